@@ -1,0 +1,107 @@
+/*
+ * lcrec.h -- C-ABI of the MI355X (gfx950) implementation of LC-Rec's
+ * item-indexing hot path.
+ *
+ * The reference (jiaozihao18/LC-Rec) is pure Python/PyTorch and has no FFI
+ * layer; the seam this library sits under is the reference's nn.Module API
+ * (SURVEY.md section 8b).  Each entry point below names the reference code it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "device" is a HIP device
+ *     pointer to a contiguous row-major buffer owned by the caller;
+ *     pointers marked "host" are ordinary host arrays (shape descriptors);
+ *   - the library allocates nothing that outlives a call: scratch space is a
+ *     caller-provided workspace whose size is returned by *_workspace();
+ *   - all work is enqueued on `stream` (a hipStream_t, NULL = default stream);
+ *     calls never synchronise the device;
+ *   - return 0 on success, a negative LCREC_E* code otherwise; the message for
+ *     the calling thread's last error is lcrec_last_error(); nothing throws;
+ *   - arithmetic contract: every contraction is one fp32 fused-multiply-add
+ *     chain over k ascending starting at 0 (v_mfma_f32_32x32x2_f32 semantics);
+ *     results are bit-identical to oracle/lcrec_oracle.c.
+ */
+#ifndef LCREC_H
+#define LCREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCREC_ABI_VERSION 1
+
+#define LCREC_OK 0
+#define LCREC_EINVAL (-1)      /* bad argument (shape, NULL pointer, unsupported size) */
+#define LCREC_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
+#define LCREC_EWORKSPACE (-3)  /* workspace too small */
+#define LCREC_EHIP (-4)        /* HIP runtime error (launch failed, no gfx950 device) */
+
+#define LCREC_MAX_LEVELS 16
+#define LCREC_MAX_LAYERS 16
+
+/* LCREC_ABI_VERSION of the loaded library. */
+int lcrec_version(void);
+
+/* Message for the last error returned on the calling thread ("" if none). */
+const char *lcrec_last_error(void);
+
+/* One MLP layer: y = [relu]( [bn]( x @ W^T + b ) ).
+ * Replaces one Dropout(p=0)/Linear/[BatchNorm1d eval]/[ReLU] group of
+ * MLPLayers.forward, index/models/layers.py:18-30,42 (nn.Linear at :23,
+ * BatchNorm1d at :26, activation at :28-30).
+ *   x [n][in_dim], W [out_dim][in_dim] (nn.Linear.weight layout), b [out_dim] or NULL,
+ *   bn_scale/bn_shift [out_dim] or both NULL: eval-mode BatchNorm folded by the
+ *   caller to y = t*scale + shift (scale = gamma/sqrt(var+eps), shift = beta - mean*scale),
+ *   y [n][out_dim].  All device pointers. */
+int lcrec_linear_forward(const float *x, int64_t n, int in_dim, const float *W, const float *b,
+                         const float *bn_scale, const float *bn_shift, int relu, int out_dim,
+                         float *y, void *stream);
+
+/* L-level residual quantisation with hard (argmin) assignment.
+ * Replaces ResidualVectorQuantizer.forward, index/models/rq.py:39-55, over
+ * VectorQuantizer.forward with use_sk=False, index/models/vq.py:63-99
+ * (distance :71-73, argmin :75, gather :87, losses :90-92, STE :95).
+ *   z          device [n][e]         latents
+ *   codebooks  device, level l is [K[l]][e] at float offset sum_{m<l} K[m]*e
+ *                                    (= torch.cat of rq.get_codebook() rows, rq.py:32-37)
+ *   K          host   [L]            codes per level, each a multiple of 32
+ *   idx_out    device [n][L] int64   (rq.py:54)
+ *   xq_out     device [n][e] or NULL sum over levels of the straight-through x_res (rq.py:48)
+ *   sse_out    device [L] double or NULL  per-level sum of (c - r)^2; the level loss of
+ *                                    vq.py:90-92 is (1+beta)*sse/(n*e)
+ *   resid_out  device [L][n][e] or NULL  residual fed into each level (input of
+ *                                    lcrec_code_stats)
+ *   workspace  device scratch of lcrec_rq_assign_workspace() bytes
+ * e must be 16, 32 or 64. */
+size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L);
+int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
+                    int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Encoder MLP + residual quantisation: item embeddings -> index tuples.
+ * Replaces RQVAE.get_indices(xs, use_sk=False), index/models/rqvae.py:68-72
+ * (encoder = MLPLayers, layers.py:42; rq = rq.py:39-55).  This is the path
+ * BASELINE.json's metric measures.
+ *   x          device [n][dims[0]]
+ *   dims       host   [n_layers+1]   in_dim, hidden sizes..., e_dim (rqvae.py:46)
+ *   W, b, bn_scale, bn_shift  host arrays of n_layers device pointers (bn_* arrays
+ *              may be NULL, or hold NULL entries for layers without BatchNorm);
+ *              ReLU follows every layer but the last (layers.py:27-30)
+ *   latent_out device [n][e] or NULL  encoder output
+ *   others     as lcrec_rq_assign */
+size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n_layers, const int *K, int L);
+int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers,
+                        const float *const *W, const float *const *b,
+                        const float *const *bn_scale, const float *const *bn_shift,
+                        const float *codebooks, const int *K, int L, int64_t *idx_out,
+                        float *latent_out, float *xq_out, double *sse_out, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCREC_H */

@@ -1,0 +1,10 @@
+"""lcrec_amd -- MI355X-native implementation of LC-Rec's item-indexing hot path.
+
+Host side mirrors the reference's module API (index/models/*.py, index/trainer.py,
+index/main.py, index/generate_indices.py); the arithmetic lives in
+csrc/liblcrec_hip.so behind the C-ABI of include/lcrec.h.
+"""
+from . import _lib, ops  # noqa: F401
+from ._lib import LcrecError  # noqa: F401
+
+__version__ = "0.1.0"

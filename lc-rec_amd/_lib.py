@@ -1,0 +1,71 @@
+"""ctypes binding of liblcrec_hip.so -- the C-ABI declared in include/lcrec.h.
+
+There is no CPU fallback: if the library has not been built (or cannot be
+loaded) every entry point raises.  Build it with ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C lc-rec_amd/csrc``.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (first, so the HIP runtime torch ships is the one this library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblcrec_hip.so")
+
+_f32p = ctypes.c_void_p
+_vp = ctypes.c_void_p
+
+
+class LcrecError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "lcrec_version": (ctypes.c_int, []),
+    "lcrec_last_error": (ctypes.c_char_p, []),
+    "lcrec_linear_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                            ctypes.c_int, _vp, _vp]),
+    "lcrec_rq_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                                    ctypes.c_int]),
+    "lcrec_rq_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
+                                       ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_encode_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                                        ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "lcrec_encode_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                           ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                           ctypes.POINTER(_vp), _vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                           _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Return the loaded library; raise LcrecError (never fall back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LcrecError(
+            f"{LIB_PATH} is not built: lcrec_amd has no CPU fallback. "
+            "Run `make -C lc-rec_amd/csrc` (hipcc, --offload-arch=gfx950).")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise LcrecError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lcrec_version() != 1:
+        raise LcrecError(f"ABI version mismatch: library {lib.lcrec_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().lcrec_last_error().decode("utf-8", "replace")
+        raise LcrecError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,116 @@
+// extern "C" surface of liblcrec_hip.so (declared in include/lcrec.h).
+#include "common.h"
+
+#include <string.h>
+
+namespace lcrec {
+
+static thread_local char g_err[512] = "";
+
+char *err_buf() { return g_err; }
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// Items per pass of the encoder chain: bounds the activation scratch
+// (2 x chunk x widest hidden layer) while keeping every GEMM launch >> 256 tiles.
+constexpr int64_t ENC_CHUNK = 131072;
+
+struct EncLayout {
+    int64_t chunk;
+    size_t act_bytes;     // one activation buffer
+    size_t latent_bytes;  // [n][e]
+    size_t rq_bytes;
+};
+
+static EncLayout enc_layout(int64_t n, const int *dims, int n_layers, const int *K, int L)
+{
+    EncLayout o;
+    o.chunk = n < ENC_CHUNK ? (n > 0 ? n : 1) : ENC_CHUNK;
+    int widest = 1;
+    for (int l = 1; l < n_layers; ++l) widest = dims[l] > widest ? dims[l] : widest;
+    o.act_bytes = align_up((size_t)o.chunk * widest * sizeof(float), 256);
+    o.latent_bytes = align_up((size_t)(n > 0 ? n : 1) * dims[n_layers] * sizeof(float), 256);
+    o.rq_bytes = rq_assign_workspace(n, dims[n_layers], K, L);
+    return o;
+}
+
+}  // namespace lcrec
+
+using namespace lcrec;
+
+LCREC_API int lcrec_version(void) { return LCREC_ABI_VERSION; }
+
+LCREC_API const char *lcrec_last_error(void) { return err_buf(); }
+
+LCREC_API int lcrec_linear_forward(const float *x, int64_t n, int in_dim, const float *W, const float *b,
+                                   const float *bn_scale, const float *bn_shift, int relu, int out_dim,
+                                   float *y, void *stream)
+{
+    return linear_forward(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, (hipStream_t)stream);
+}
+
+LCREC_API size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L)
+{
+    return rq_assign_workspace(n, e, K, L);
+}
+
+LCREC_API int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
+                              int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    return rq_assign(z, n, e, codebooks, K, L, idx_out, xq_out, sse_out, resid_out, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+LCREC_API size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n_layers, const int *K, int L)
+{
+    if (!dims || n_layers < 1 || n_layers > LCREC_MAX_LAYERS || !K || L < 1) return 0;
+    EncLayout o = enc_layout(n, dims, n_layers, K, L);
+    return 2 * o.act_bytes + o.latent_bytes + o.rq_bytes;
+}
+
+LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers,
+                                  const float *const *W, const float *const *b,
+                                  const float *const *bn_scale, const float *const *bn_shift,
+                                  const float *codebooks, const int *K, int L, int64_t *idx_out,
+                                  float *latent_out, float *xq_out, double *sse_out, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    if (!x || !dims || !W || !b || !codebooks || !K || !idx_out)
+        return fail(LCREC_EINVAL, "encode_assign: NULL pointer");
+    if (n_layers < 1 || n_layers > LCREC_MAX_LAYERS)
+        return fail(LCREC_EINVAL, "encode_assign: n_layers=%d out of range", n_layers);
+    if (n < 0) return fail(LCREC_EINVAL, "encode_assign: n < 0");
+    if (n == 0) return LCREC_OK;
+    const size_t need = lcrec_encode_assign_workspace(n, dims, n_layers, K, L);
+    if (!workspace || workspace_bytes < need)
+        return fail(LCREC_EWORKSPACE, "encode_assign: workspace %zu B < required %zu B", workspace_bytes, need);
+    const EncLayout o = enc_layout(n, dims, n_layers, K, L);
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *act[2] = {reinterpret_cast<float *>(ws), reinterpret_cast<float *>(ws + o.act_bytes)};
+    float *latent = latent_out ? latent_out : reinterpret_cast<float *>(ws + 2 * o.act_bytes);
+    void *rq_ws = ws + 2 * o.act_bytes + o.latent_bytes;
+    const int e = dims[n_layers];
+    hipStream_t s = (hipStream_t)stream;
+
+    for (int64_t i0 = 0; i0 < n; i0 += o.chunk) {
+        const int64_t m = (n - i0 < o.chunk) ? n - i0 : o.chunk;
+        const float *src = x + i0 * dims[0];
+        for (int l = 0; l < n_layers; ++l) {
+            const bool last = l == n_layers - 1;
+            float *dst = last ? latent + i0 * e : act[l & 1];
+            int rc = linear_forward(src, m, dims[l], W[l], b[l], bn_scale ? bn_scale[l] : nullptr,
+                                    bn_shift ? bn_shift[l] : nullptr, last ? 0 : 1, dims[l + 1], dst, s);
+            if (rc) return rc;
+            src = dst;
+        }
+    }
+    return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, sse_out, nullptr, rq_ws, o.rq_bytes, s);
+}

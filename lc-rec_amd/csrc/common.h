@@ -1,0 +1,41 @@
+// Internal helpers shared by the HIP translation units of liblcrec_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, fp32 MFMA, 160 KB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lcrec.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LCREC_API extern "C" __attribute__((visibility("default")))
+
+namespace lcrec {
+
+// thread-local last-error text (lcrec_last_error)
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LCREC_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return LCREC_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// kernels' launchers (host side, enqueue only)
+int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const float *b,
+                   const float *bn_scale, const float *bn_shift, int relu, int out_dim, float *y,
+                   hipStream_t stream);
+
+size_t rq_assign_workspace(int64_t n, int e, const int *K, int L);
+int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
+              int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out, void *workspace,
+              size_t workspace_bytes, hipStream_t stream);
+
+}  // namespace lcrec

@@ -1,0 +1,400 @@
+// L-level residual quantiser, hard (argmin) assignment, for gfx950.
+//
+// Replaces ResidualVectorQuantizer.forward (reference index/models/rq.py:39-55)
+// over VectorQuantizer.forward with use_sk=False (index/models/vq.py:63-99):
+// distance (:71-73), argmin (:75), gather (:87), losses (:90-92), STE (:95),
+// residual update (rq.py:47-48) -- all L levels in one launch when the
+// codebooks fit in LDS, with the residual living in registers throughout.
+//
+// Mapping onto the hardware
+//   * Codebooks (and their squared norms) are staged once per workgroup into
+//     LDS; workgroups are persistent and stride over 64-item tiles per wave.
+//   * The -2 x.C term is v_mfma_f32_32x32x2_f32 with the CODEBOOK as the A
+//     operand and the residuals as B, so the 32x32 result tile has the item on
+//     the lane and 16 codes in the lane's registers: the argmin over codes is a
+//     register-local scan plus ONE cross-half exchange (v_permlane32_swap).
+//   * One lane owns one item (its E residual floats live in its VGPRs).  The
+//     B operands of the two 32-item groups of a wave are produced from those
+//     registers by v_permlane32_swap: swap(r[2s], r[2s+1]) yields, in one
+//     instruction, {r_lo[2s] | r_lo[2s+1]} for items 0-31 and
+//     {r_hi[2s] | r_hi[2s+1]} for items 32-63 -- exactly the k = 2s / 2s+1
+//     split a 32x32x2 MFMA wants.
+//   * LDS rows store a code de-interleaved ([even k | odd k]) and padded by 4
+//     floats: a lane's A operand for all E/2 MFMA steps of a 32-code block is
+//     E/8 ds_read_b128, conflict-free (row stride E+4 floats puts 16
+//     consecutive rows on 16 distinct 4-bank slots).
+//
+// Arithmetic contract = oracle/lcrec_oracle.c (assign_one, lcrec_oracle_rq_assign):
+//   xx = chain_k r[k]^2;  cc[j] = chain_k C[j][k]^2;  dot = chain_k r[k]*C[j][k]  (fp32 fma chains, k ascending)
+//   d[j] = (xx + cc[j]) - 2*dot;  argmin takes the first minimum;
+//   t = c - r;  s = r + t;  x_q += s;  r -= s.
+#include "common.h"
+
+namespace lcrec {
+
+struct RqParams {
+    const float *z_in;     // [n][E] residual entering level l0
+    const float *cb;       // codebook rows of levels l0..l1-1, contiguous [rows][E]
+    int64_t n;
+    int l0, l1, L;
+    int K[LCREC_MAX_LEVELS];        // codes per level (absolute level index)
+    int row_off[LCREC_MAX_LEVELS];  // first LDS row of a level (absolute level index)
+    int rows;                       // total rows staged by this launch
+    int64_t *idx_out;      // [n][L]
+    float *xq;             // [n][E] in/out (read when l0 > 0), or NULL
+    float *resid_next;     // [n][E] residual after level l1-1, or NULL
+    float *resid_levels;   // [L][n][E] residual entering each level, or NULL
+    double *sse_partial;   // [gridDim.x][L], or NULL
+};
+
+__device__ __forceinline__ void swap32(float a, float b, float &lo_pair, float &hi_pair)
+{
+    // lanes 32-63 of `a` exchange with lanes 0-31 of `b`:
+    //   lo_pair = {a.lo | b.lo},  hi_pair = {a.hi | b.hi}
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    lo_pair = __uint_as_float(r[0]);
+    hi_pair = __uint_as_float(r[1]);
+}
+
+template <int E, int THREADS, bool WANT_XQ>
+__global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
+{
+    constexpr int S = E + 4;   // padded LDS row (floats)
+    constexpr int H = E / 2;   // MFMA steps per 32-code block
+    constexpr int WAVES = THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *cbs = smem;                       // [rows][S]
+    float *ccs = smem + (size_t)p.rows * S;  // [rows]
+    double *wave_sse = reinterpret_cast<double *>(ccs + ((p.rows + 3) & ~3));  // [WAVES][L]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+
+    // ---- stage codebooks: global [row][E] -> LDS [row][even k | odd k | pad]
+    for (int q = tid; q < p.rows * (E / 8); q += THREADS) {
+        const int row = q / (E / 8), g = q % (E / 8);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cb + (size_t)row * E + g * 8);
+        const f32x4 a = src[0], b = src[1];
+        f32x4 ev = {a[0], a[2], b[0], b[2]};
+        f32x4 od = {a[1], a[3], b[1], b[3]};
+        *reinterpret_cast<f32x4 *>(cbs + row * S + g * 4) = ev;
+        *reinterpret_cast<f32x4 *>(cbs + row * S + H + g * 4) = od;
+    }
+    for (int q = tid; q < WAVES * p.L; q += THREADS) wave_sse[q] = 0.0;
+    __syncthreads();
+    for (int row = tid; row < p.rows; row += THREADS) {
+        const float *cr = cbs + row * S;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            a = __builtin_fmaf(cr[k], cr[k], a);          // k even = 2k'
+            a = __builtin_fmaf(cr[H + k], cr[H + k], a);  // k odd  = 2k'+1
+        }
+        ccs[row] = a;
+    }
+    __syncthreads();
+
+    const int64_t tiles = (p.n + 63) / 64;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + wave, GW = (int64_t)gridDim.x * WAVES;
+
+    for (int64_t tile = gw; tile < tiles; tile += GW) {
+        const int64_t item = tile * 64 + lane;
+        const bool valid = item < p.n;
+
+        float r[E], xq[WANT_XQ ? E : 1];
+        if (valid) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.z_in + item * E);
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) {
+                const f32x4 v = src[q];
+                r[4 * q] = v[0]; r[4 * q + 1] = v[1]; r[4 * q + 2] = v[2]; r[4 * q + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) r[k] = 0.f;
+        }
+        if (WANT_XQ) {
+            if (p.l0 > 0 && valid) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(p.xq + item * E);
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    const f32x4 v = src[q];
+                    xq[4 * q] = v[0]; xq[4 * q + 1] = v[1]; xq[4 * q + 2] = v[2]; xq[4 * q + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (WANT_XQ ? E : 1); ++k) xq[k] = 0.f;
+            }
+        }
+
+        for (int l = p.l0; l < p.l1; ++l) {
+            const int ro = p.row_off[l];
+            const int nblk = p.K[l] >> 5;
+
+            if (p.resid_levels && valid) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(p.resid_levels + ((size_t)l * p.n + item) * E);
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    f32x4 v = {r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+                    dst[q] = v;
+                }
+            }
+
+            // xx = chain_k r[k]^2 for the lane's own item, then handed to both halves
+            float xx = 0.f;
+#pragma unroll
+            for (int k = 0; k < E; ++k) xx = __builtin_fmaf(r[k], r[k], xx);
+            float xx0, xx1;
+            swap32(xx, xx, xx0, xx1);   // xx0 = {xx.lo | xx.lo}: items 0-31; xx1: items 32-63
+
+            float b0[H], b1[H];
+#pragma unroll
+            for (int s = 0; s < H; ++s) swap32(r[2 * s], r[2 * s + 1], b0[s], b1[s]);
+
+            float best0 = __builtin_inff(), best1 = __builtin_inff();
+            int bi0 = 0, bi1 = 0;
+
+            for (int b = 0; b < nblk; ++b) {
+                const float *arow = cbs + (ro + b * 32 + c) * S + h * H;
+                float af[H];
+#pragma unroll
+                for (int q = 0; q < H / 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
+                    af[4 * q] = v[0]; af[4 * q + 1] = v[1]; af[4 * q + 2] = v[2]; af[4 * q + 3] = v[3];
+                }
+                float ccv[16];
+                const float *ccb = ccs + ro + b * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(ccb + 8 * q);
+                    ccv[4 * q] = v[0]; ccv[4 * q + 1] = v[1]; ccv[4 * q + 2] = v[2]; ccv[4 * q + 3] = v[3];
+                }
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { acc0[t] = 0.f; acc1[t] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < H; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b0[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b1[s], acc1, 0, 0, 0);
+                }
+                // register t of the tile is code (t&3) + 8*(t>>2) + 4*h of this block: ascending in t
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int code = b * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                    const float t0 = xx0 + ccv[t];
+                    const float d0 = t0 - 2.0f * acc0[t];
+                    const bool lt0 = d0 < best0;
+                    best0 = lt0 ? d0 : best0;
+                    bi0 = lt0 ? code : bi0;
+                    const float t1 = xx1 + ccv[t];
+                    const float d1 = t1 - 2.0f * acc1[t];
+                    const bool lt1 = d1 < best1;
+                    best1 = lt1 ? d1 : best1;
+                    bi1 = lt1 ? code : bi1;
+                }
+            }
+
+            // bring both half-partials of the lane's own item home:
+            //   dA/iA = partial over the h=0 codes, dB/iB = partial over the h=1 codes
+            float dA, dB, fA, fB;
+            swap32(best0, best1, dA, dB);
+            swap32(__int_as_float(bi0), __int_as_float(bi1), fA, fB);
+            const int iA = __float_as_int(fA), iB = __float_as_int(fB);
+            const bool takeB = (dB < dA) || (dB == dA && iB < iA);
+            const int bi = takeB ? iB : iA;
+
+            if (valid) p.idx_out[item * p.L + l] = (int64_t)bi;
+
+            // gather the winning code (LDS row is [even k | odd k])
+            const float *crow = cbs + (ro + bi) * S;
+            float cv[E];
+#pragma unroll
+            for (int q = 0; q < H / 4; ++q) {
+                const f32x4 ev = *reinterpret_cast<const f32x4 *>(crow + 4 * q);
+                const f32x4 od = *reinterpret_cast<const f32x4 *>(crow + H + 4 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    cv[2 * (4 * q + t)] = ev[t];
+                    cv[2 * (4 * q + t) + 1] = od[t];
+                }
+            }
+            float sse = 0.f;
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const float t = cv[k] - r[k];
+                sse = __builtin_fmaf(t, t, sse);
+                const float s = r[k] + t;
+                if (WANT_XQ) xq[k] = xq[k] + s;
+                r[k] = r[k] - s;
+            }
+            if (p.sse_partial) {
+                double v = valid ? (double)sse : 0.0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+                if (lane == 0) wave_sse[wave * p.L + l] += v;
+            }
+        }
+
+        if (valid) {
+            if (WANT_XQ) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(p.xq + item * E);
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    f32x4 v = {xq[4 * q], xq[4 * q + 1], xq[4 * q + 2], xq[4 * q + 3]};
+                    dst[q] = v;
+                }
+            }
+            if (p.resid_next) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(p.resid_next + item * E);
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    f32x4 v = {r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+                    dst[q] = v;
+                }
+            }
+        }
+    }
+
+    if (p.sse_partial) {
+        __syncthreads();
+        for (int l = p.l0 + tid; l < p.l1; l += THREADS) {
+            double v = 0.0;
+            for (int w = 0; w < WAVES; ++w) v += wave_sse[w * p.L + l];
+            p.sse_partial[(size_t)blockIdx.x * p.L + l] = v;
+        }
+    }
+}
+
+// sse_out[l] = sum over blocks (fixed order) of the per-block partials
+__global__ void rq_sse_finalize_kernel(const double *partial, int blocks, int L, int l0, int l1, double *sse_out)
+{
+    const int l = l0 + threadIdx.x;
+    if (l >= l1) return;
+    double v = 0.0;
+    for (int b = 0; b < blocks; ++b) v += partial[(size_t)b * L + l];
+    sse_out[l] = v;
+}
+
+// ---------------------------------------------------------------- host side
+
+constexpr size_t LDS_BUDGET = 160 * 1024;
+constexpr int MAX_GRID = 256;   // one persistent workgroup per CU
+
+static size_t lds_bytes(int rows, int E, int L, int waves)
+{
+    return ((size_t)rows * (E + 4) + ((rows + 3) & ~3)) * sizeof(float) + (size_t)waves * L * sizeof(double);
+}
+
+static int threads_for(int e, int64_t n)
+{
+    if (e == 64) return 256;             // 512-register budget per lane
+    return n >= 256 * 512 ? 512 : 256;   // small inputs: more, smaller workgroups
+}
+
+static int grid_for(int64_t n, int threads)
+{
+    const int64_t per_block = threads;   // 64 items per wave per iteration
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > MAX_GRID) g = MAX_GRID;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+size_t rq_assign_workspace(int64_t n, int e, const int *K, int L)
+{
+    (void)K;
+    // [n][e] ping-pong residual for multi-launch configurations + SSE partials
+    size_t resid = align_up((size_t)(n > 0 ? n : 1) * e * sizeof(float), 256);
+    size_t part = align_up((size_t)MAX_GRID * L * sizeof(double), 256);
+    return 2 * resid + part;
+}
+
+template <int E, int THREADS, bool WANT_XQ>
+static int launch_one(const RqParams &p, int grid, size_t lds, hipStream_t stream)
+{
+    auto kern = rq_assign_kernel<E, THREADS, WANT_XQ>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(LCREC_EHIP, "rq_assign: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, p);
+    return check_launch("rq_assign_kernel");
+}
+
+template <int E>
+static int dispatch(const RqParams &p, int threads, int grid, size_t lds, bool want_xq, hipStream_t stream)
+{
+    if (threads == 512) {
+        if constexpr (E == 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e=64 runs 256-thread workgroups");
+        else return want_xq ? launch_one<E, 512, true>(p, grid, lds, stream) : launch_one<E, 512, false>(p, grid, lds, stream);
+    }
+    return want_xq ? launch_one<E, 256, true>(p, grid, lds, stream) : launch_one<E, 256, false>(p, grid, lds, stream);
+}
+
+int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
+              int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out, void *workspace,
+              size_t workspace_bytes, hipStream_t stream)
+{
+    if (!z || !codebooks || !K || !idx_out) return fail(LCREC_EINVAL, "rq_assign: NULL pointer");
+    if (n < 0 || L < 1 || L > LCREC_MAX_LEVELS) return fail(LCREC_EINVAL, "rq_assign: bad n=%lld or L=%d", (long long)n, L);
+    if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e_dim=%d (supported: 16, 32, 64)", e);
+    if (((uintptr_t)z | (uintptr_t)codebooks | (uintptr_t)xq_out | (uintptr_t)resid_out) & 15)
+        return fail(LCREC_EINVAL, "rq_assign: buffers must be 16-byte aligned");
+    const int threads = threads_for(e, n);
+    const int waves = threads / 64;
+    for (int l = 0; l < L; ++l) {
+        if (K[l] <= 0 || K[l] % 32) return fail(LCREC_EUNSUPPORTED, "rq_assign: K[%d]=%d is not a positive multiple of 32", l, K[l]);
+        if (lds_bytes(K[l], e, L, waves) > LDS_BUDGET)
+            return fail(LCREC_EUNSUPPORTED, "rq_assign: level %d (K=%d, e=%d) does not fit in 160 KB of LDS", l, K[l], e);
+    }
+    if (n == 0) return LCREC_OK;
+    if (workspace_bytes < rq_assign_workspace(n, e, K, L) || !workspace)
+        return fail(LCREC_EWORKSPACE, "rq_assign: workspace %zu B < required %zu B", workspace_bytes, rq_assign_workspace(n, e, K, L));
+
+    const size_t resid_bytes = align_up((size_t)n * e * sizeof(float), 256);
+    float *ping = reinterpret_cast<float *>(workspace);
+    float *pong = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + resid_bytes);
+    double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 2 * resid_bytes);
+    const int grid = grid_for(n, threads);
+
+    // Greedily pack consecutive levels into launches whose codebooks fit in LDS.
+    int64_t cb_off = 0;
+    const float *zin = z;
+    int l0 = 0;
+    while (l0 < L) {
+        RqParams p = {};
+        int rows = 0, l1 = l0;
+        while (l1 < L && lds_bytes(rows + K[l1], e, L, waves) <= LDS_BUDGET) {
+            p.row_off[l1] = rows;
+            rows += K[l1];
+            ++l1;
+        }
+        for (int l = 0; l < L; ++l) p.K[l] = K[l];
+        p.z_in = zin;
+        p.cb = codebooks + cb_off;
+        p.n = n; p.l0 = l0; p.l1 = l1; p.L = L; p.rows = rows;
+        p.idx_out = idx_out;
+        p.xq = xq_out;
+        p.resid_levels = resid_out;
+        p.sse_partial = sse_out ? partial : nullptr;
+        float *next = nullptr;
+        if (l1 < L) next = (zin == ping) ? pong : ping;
+        p.resid_next = next;
+        const size_t lds = lds_bytes(rows, e, L, waves);
+        int rc;
+        if (e == 16) rc = dispatch<16>(p, threads, grid, lds, xq_out != nullptr, stream);
+        else if (e == 32) rc = dispatch<32>(p, threads, grid, lds, xq_out != nullptr, stream);
+        else rc = dispatch<64>(p, threads, grid, lds, xq_out != nullptr, stream);
+        if (rc) return rc;
+        if (sse_out) {
+            hipLaunchKernelGGL(rq_sse_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, grid, L, l0, l1, sse_out);
+            rc = check_launch("rq_sse_finalize_kernel");
+            if (rc) return rc;
+        }
+        for (int l = l0; l < l1; ++l) cb_off += (int64_t)K[l] * e;
+        zin = next;
+        l0 = l1;
+    }
+    return LCREC_OK;
+}
+
+}  // namespace lcrec
