@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: item-embeddings/sec through 4-level RQ encode+assign.
+
+One "step" = one pass of RQVAE.get_indices(use_sk=False) semantics (reference
+index/models/rqvae.py:68-72) over the rank's shard of synthetic item embeddings
+already resident in HBM: fp32 [n, d_in] -> int64 [n, L].
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workloads (BASELINE.json configs):
+  c3 (default)  1M items x 768-d per GPU, 4 levels x 256 codes, e_dim 32, MLP 2048-1024-512-256-128-64
+  c4            1.25M items x 4096-d per GPU (10M over 8 GPUs), same model
+  c2            16 859 items x 4096-d (Games-sized)
+Items shard across ranks with no data-path collective (weak scaling: fixed items per GPU).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP events on the launch
+stream, inside the timed region) and, at N=1, `cpu_baseline` (the torch-CPU restatement of the
+reference path timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "c3": dict(items=1_000_000, in_dim=768, name="C3 synthetic 1M x 768-d, 4x256 codes"),
+    "c4": dict(items=1_250_000, in_dim=4096, name="C4 synthetic 10M x 4096-d over 8 GPUs (1.25M per GPU), 4x256 codes"),
+    "c2": dict(items=16_859, in_dim=4096, name="C2 Games-sized 16859 x 4096-d, 4x256 codes"),
+}
+HIDDEN = [2048, 1024, 512, 256, 128, 64]   # index/run.sh:15
+E_DIM = 32                                  # index/run.sh:10
+CODES = [256, 256, 256, 256]                # index/run.sh:13
+PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBPS = 8000.0
+
+
+def synth_model(in_dim, device, seed=2024):
+    """Random-init encoder in the reference's init (xavier_normal_ weights, zero bias;
+    layers.py:33-40) and data-scale codebooks (rows sampled from each level's residuals,
+    the stand-in for k-means named in SURVEY.md section 8d)."""
+    import lcrec_amd
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    dims = [in_dim] + HIDDEN + [E_DIM]
+    Ws, bs = [], []
+    for l in range(len(dims) - 1):
+        std = (2.0 / (dims[l] + dims[l + 1])) ** 0.5
+        Ws.append(torch.randn((dims[l + 1], dims[l]), generator=g, device=device, dtype=torch.float32) * std)
+        bs.append(torch.zeros(dims[l + 1], device=device, dtype=torch.float32))
+    probe = torch.randn((8192, in_dim), generator=g, device=device, dtype=torch.float32)
+    z = probe
+    for l in range(len(Ws)):
+        z = lcrec_amd.ops.linear_forward(z, Ws[l], bs[l], relu=l != len(Ws) - 1)
+    cbs, resid = [], z
+    for K in CODES:
+        pick = torch.randperm(resid.shape[0], generator=g, device=device)[:K]
+        cbs.append(resid[pick].clone())
+        flat, ks = lcrec_amd.ops.flatten_codebooks(cbs)
+        _, xq, _, _ = lcrec_amd.ops.rq_assign(z, flat, ks, want_xq=True)
+        resid = z - xq
+    return dims, Ws, bs, cbs
+
+
+def host_cores():
+    """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota.
+    A one-GPU box exposes all host CPUs but grants a share of them; with no readable quota on a
+    large host we take 16, the share a one-GPU box gets."""
+    env = os.environ.get("LCREC_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                period = int(fh.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    elif n > 64:
+        n = 16
+    return n
+
+
+def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=12.0):
+    """The reference's CPU path (torch CPU ops of rqvae.py:68-72, restated in oracle/torch_ref.py),
+    batch 4096, timed on this host's cores on a bounded sample."""
+    from oracle import torch_ref
+    spec = torch_ref.Spec(dims[0], CODES, dims[-1], dims[1:-1], sk_epsilons=[0.0] * len(CODES))
+    sd = {}
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        slot = torch_ref.linear_slot(l, False)
+        sd[f"encoder.mlp_layers.{slot}.weight"] = W.cpu()
+        sd[f"encoder.mlp_layers.{slot}.bias"] = b.cpu()
+    for l, c in enumerate(cbs):
+        sd[f"rq.vq_layers.{l}.embedding.weight"] = c.cpu()
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    batch = 4096
+    torch_ref.get_indices(spec, sd, x_cpu[:batch])          # warm-up
+    done, t0 = 0, time.perf_counter()
+    while done < x_cpu.shape[0]:
+        torch_ref.get_indices(spec, sd, x_cpu[done:done + batch])
+        done += min(batch, x_cpu.shape[0] - done)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "items/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {done} rows of the same synthetic tensor, batch 4096, fp32, "
+                      f"oracle/torch_ref.get_indices (torch CPU ops of rqvae.py:68-72)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--items", type=int, default=0, help="override items per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a MI355X: no HIP device visible (lcrec_amd has no CPU path)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import lcrec_amd
+    from lcrec_amd import ops
+    lcrec_amd._lib.load()
+
+    wl = WORKLOADS[args.workload]
+    n = args.items or wl["items"]
+    dims, Ws, bs, cbs = synth_model(wl["in_dim"], device)
+    flat, ks = ops.flatten_codebooks(cbs)
+    g = torch.Generator(device=device)
+    g.manual_seed(2024 + rank)
+    x = torch.randn((n, wl["in_dim"]), generator=g, device=device, dtype=torch.float32)
+
+    def step():
+        return ops.encode_assign(x, Ws, bs, flat, ks)[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        idx = step()
+    barrier()
+    ops.trace_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    trace = ops.trace_collect()
+    ops.trace_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the 128x128-tile fp32-MFMA GEMM (layers with more than 64 outputs)
+    macs_dom = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1) if dims[l + 1] > 64)
+    macs_all = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1)) + sum(E_DIM * k for k in ks)
+    launches, total_ms = trace.get("linear_fwd_128x128", (0, 0.0))
+    flops_dom_total = 2.0 * macs_dom * n * args.steps
+    achieved = flops_dom_total / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_linear_fwd_128x128.json")
+    if os.path.exists(pmc_file):
+        with open(pmc_file) as fh:
+            traffic = json.load(fh).get(args.workload, {}).get("hbm_bytes_per_launch")
+    roofline = {
+        "kernel": "linear_fwd_128x128", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+        "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
+        "flops_per_launch": (flops_dom_total / launches) if launches else None,
+        "kernel_ms": {k: round(v[1], 3) for k, v in trace.items()},
+    }
+
+    if rank == 0:
+        total_items = n * world * args.steps
+        value = total_items / elapsed
+        out = {
+            "metric": "item-embeddings/sec through 4-level RQ encode+assign", "value": value, "unit": "items/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "items_per_gpu": n, "in_dim": wl["in_dim"], "mlp": HIDDEN,
+                       "e_dim": E_DIM, "levels": len(ks), "codes_per_level": ks[0], "sharding": f"items/{world}",
+                       "flop_per_item": 2 * macs_all, "bytes_per_item": 4 * wl["in_dim"] + 8 * len(ks)},
+            "roofline": roofline,
+            "e2e_mfma_frac": value / world * 2 * macs_all / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "io_gbps": value / world * (4 * wl["in_dim"] + 8 * len(ks)) / 1e9,
+        }
+        if world == 1:
+            # parity spot check (not timed): 1024 rows against the bit-exact C oracle
+            from oracle import cpu_oracle
+            m = min(1024, n)
+            want = cpu_oracle.encode_assign(x[:m].cpu().numpy(), [w.cpu().numpy() for w in Ws],
+                                            [b.cpu().numpy() for b in bs], [c.cpu().numpy() for c in cbs],
+                                            threads=host_cores())["idx"]
+            out["parity_rows_checked"] = m
+            out["parity_mismatch_rows"] = int((idx[:m].cpu().numpy() != want).any(axis=1).sum())
+            if not args.no_cpu_baseline:
+                sample = x[: min(n, 200_000)].cpu()
+                out["cpu_baseline"] = cpu_baseline(sample, dims, Ws, bs, cbs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

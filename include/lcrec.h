@@ -101,6 +101,21 @@ int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers
                         float *latent_out, float *xq_out, double *sse_out, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* Kernel tracing (diagnostic; the reference has no tracing on this path -- its only
+ * timing is wall-clock per epoch, index/trainer.py:193-195).  While enabled, every
+ * kernel this library launches is bracketed by a pair of hipEvents recorded on the
+ * launch stream; lcrec_trace_collect() waits for the recorded events, sums elapsed
+ * time per kernel and clears the log.  bench.py uses it to price the dominant
+ * kernel against its roofline inside the timed region. */
+typedef struct {
+    const char *kernel;   /* static string, e.g. "linear_fwd_128x128" */
+    int64_t launches;
+    double total_ms;
+} lcrec_trace_entry;
+int lcrec_trace_enable(int on);
+/* Returns the number of entries written (<= capacity), or a negative LCREC_E* code. */
+int lcrec_trace_collect(lcrec_trace_entry *out, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,14 @@ _SIGNATURES = {
                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                            ctypes.POINTER(_vp), _vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                            _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_trace_enable": (ctypes.c_int, [ctypes.c_int]),
+    "lcrec_trace_collect": (ctypes.c_int, [_vp, ctypes.c_int]),
 }
+
+
+class TraceEntry(ctypes.Structure):
+    _fields_ = [("kernel", ctypes.c_char_p), ("launches", ctypes.c_int64), ("total_ms", ctypes.c_double)]
+
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -3,6 +3,9 @@
 
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 namespace lcrec {
 
 static thread_local char g_err[512] = "";
@@ -16,6 +19,32 @@ int fail(int code, const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+const char *const kKernelNames[K_COUNT] = {"linear_fwd_128x128", "linear_fwd_128x64", "linear_fwd_128x32",
+                                           "rq_assign", "rq_sse_finalize"};
+
+struct TraceRec { int kernel; hipEvent_t start, stop; };
+static std::mutex g_trace_mu;
+static std::vector<TraceRec> g_trace;
+static bool g_trace_on = false;
+
+bool trace_on() { return g_trace_on; }
+
+void trace_begin(int kernel, hipStream_t stream)
+{
+    TraceRec r;
+    r.kernel = kernel;
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+    (void)hipEventRecord(r.start, stream);
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    g_trace.push_back(r);
+}
+
+void trace_end(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    if (!g_trace.empty()) (void)hipEventRecord(g_trace.back().stop, stream);
 }
 
 // Items per pass of the encoder chain: bounds the activation scratch
@@ -113,4 +142,36 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
         }
     }
     return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, sse_out, nullptr, rq_ws, o.rq_bytes, s);
+}
+
+LCREC_API int lcrec_trace_enable(int on)
+{
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    for (auto &r : g_trace) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    g_trace.clear();
+    g_trace_on = on != 0;
+    return LCREC_OK;
+}
+
+LCREC_API int lcrec_trace_collect(lcrec_trace_entry *out, int capacity)
+{
+    if (!out || capacity < 1) return fail(LCREC_EINVAL, "trace_collect: no output buffer");
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    int64_t launches[K_COUNT] = {0};
+    double ms[K_COUNT] = {0.0};
+    for (auto &r : g_trace) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(r.stop);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, r.start, r.stop);
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+        if (e != hipSuccess) { g_trace.clear(); return fail(LCREC_EHIP, "trace_collect: %s", hipGetErrorString(e)); }
+        launches[r.kernel] += 1;
+        ms[r.kernel] += t;
+    }
+    g_trace.clear();
+    int n = 0;
+    for (int k = 0; k < K_COUNT && n < capacity; ++k)
+        if (launches[k]) { out[n].kernel = kKernelNames[k]; out[n].launches = launches[k]; out[n].total_ms = ms[k]; ++n; }
+    return n;
 }

@@ -26,6 +26,21 @@ inline int check_launch(const char *what)
     return LCREC_OK;
 }
 
+// Kernel ids for lcrec_trace_*.
+enum KernelId { K_LINEAR_128x128 = 0, K_LINEAR_128x64, K_LINEAR_128x32, K_RQ_ASSIGN, K_RQ_SSE_FINALIZE, K_COUNT };
+extern const char *const kKernelNames[K_COUNT];
+bool trace_on();
+void trace_begin(int kernel, hipStream_t stream);
+void trace_end(hipStream_t stream);
+
+// Brackets the launches made in its scope with hipEvents when tracing is enabled.
+struct TraceScope {
+    hipStream_t s;
+    bool on;
+    TraceScope(int kernel, hipStream_t stream) : s(stream), on(trace_on()) { if (on) trace_begin(kernel, s); }
+    ~TraceScope() { if (on) trace_end(s); }
+};
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // kernels' launchers (host side, enqueue only)

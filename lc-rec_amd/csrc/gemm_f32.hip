@@ -178,6 +178,7 @@ static int launch_linear(const float *x, int64_t n, int in_dim, const float *W, 
     const int bn_blocks = (out_dim + BN - 1) / BN;
     const int64_t grid = bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
+    TraceScope trace(BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
     hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN>), dim3((unsigned)grid), dim3(256), 0,
                        stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks);
     return check_launch("linear_fwd_kernel");

@@ -316,6 +316,7 @@ static int launch_one(const RqParams &p, int grid, size_t lds, hipStream_t strea
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(LCREC_EHIP, "rq_assign: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+    TraceScope trace(K_RQ_ASSIGN, stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, p);
     return check_launch("rq_assign_kernel");
 }
@@ -386,6 +387,7 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
         else rc = dispatch<64>(p, threads, grid, lds, xq_out != nullptr, stream);
         if (rc) return rc;
         if (sse_out) {
+            TraceScope trace(K_RQ_SSE_FINALIZE, stream);
             hipLaunchKernelGGL(rq_sse_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, grid, L, l0, l1, sse_out);
             rc = check_launch("rq_sse_finalize_kernel");
             if (rc) return rc;

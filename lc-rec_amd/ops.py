@@ -139,3 +139,17 @@ def encode_assign(x, weights, biases, codebooks_flat, ks, bn_scales=None, bn_shi
                                      _ptr(latent), _ptr(xq), _ptr(sse), _ptr(ws), ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_encode_assign")
     return idx, latent, xq, sse
+
+
+def trace_enable(on=True):
+    """Bracket every kernel launch with hipEvents (include/lcrec.h, lcrec_trace_enable)."""
+    _lib.check(_lib.load().lcrec_trace_enable(int(bool(on))), "lcrec_trace_enable")
+
+
+def trace_collect():
+    """{kernel name: (launches, total_ms)} since trace_enable(); waits for the recorded events."""
+    buf = (_lib.TraceEntry * 32)()
+    n = _lib.load().lcrec_trace_collect(ctypes.cast(buf, ctypes.c_void_p), 32)
+    if n < 0:
+        _lib.check(n, "lcrec_trace_collect")
+    return {buf[i].kernel.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(n)}

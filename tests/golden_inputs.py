@@ -1,0 +1,100 @@
+"""Seeded input recipes shared by oracle/make_golden.py (which feeds them to the imported
+reference) and the tests (which feed them to the oracle / the HIP path).
+
+numpy's legacy RandomState streams are frozen across numpy versions, so the large inputs
+(weights, codebooks, embeddings) are regenerated from seeds instead of being committed; the
+golden files under tests/golden/ hold the reference's OUTPUTS (and the few inputs that came
+from torch's RNG)."""
+import numpy as np
+
+RUN_SH_LAYERS = [2048, 1024, 512, 256, 128, 64]   # reference index/run.sh:15
+
+
+def rs(seed):
+    return np.random.RandomState(seed)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---------------------------------------------------------------- F1: RQ known-answer test
+def rq_kat(levels, codes, e=32, n=512, seed=100):
+    r = rs(seed + levels * 1000 + codes)
+    z = f32(r.standard_normal((n, e)))
+    cbs = [f32(r.standard_normal((codes, e)) * (0.7 ** l)) for l in range(levels)]
+    return z, cbs
+
+
+# ---------------------------------------------------------------- F2: exact ties
+def tie_case(seed=7, n=1024, K=256, e=32):
+    """Small integers: every product and partial sum is exact in fp32 in ANY summation order,
+    so equal distances are exactly equal and argmin's first-index rule is what is tested."""
+    r = rs(seed)
+    cb = f32(r.randint(-3, 4, size=(K, e)))
+    cb[100] = cb[5]
+    cb[200] = cb[5]
+    cb[37] = cb[36]
+    cb[255] = cb[0]
+    z = f32(cb[r.randint(0, K, size=n)] + r.randint(-1, 2, size=(n, e)))
+    z[:8] = cb[[5, 100, 200, 36, 37, 0, 255, 5]]       # exact hits on duplicated codes
+    z[8] = (cb[10] + cb[11]) / 2                         # exact midpoint (halves are exact in fp32)
+    return z, cb
+
+
+# ---------------------------------------------------------------- F3: Sinkhorn
+def sinkhorn_case(B, K=256, seed=300):
+    r = rs(seed + B)
+    z = f32(r.standard_normal((B, 32)))
+    cb = f32(r.standard_normal((K, 32)) * 0.8)
+    return z, cb
+
+
+# ---------------------------------------------------------------- F8: full-size encoder
+def encoder_weights(dims, seed=800, bn=False):
+    """Xavier-normal-scaled weights (layers.py:33-40 uses xavier_normal_; the draw itself comes
+    from numpy here), small non-zero biases, and -- for bn -- random eval-mode statistics."""
+    r = rs(seed + dims[0])
+    Ws, bs, bns = [], [], []
+    nl = len(dims) - 1
+    for l in range(nl):
+        std = np.sqrt(2.0 / (dims[l] + dims[l + 1]))
+        Ws.append(f32(r.standard_normal((dims[l + 1], dims[l])) * std))
+        bs.append(f32(0.02 * r.standard_normal(dims[l + 1])))
+        if bn and l != nl - 1:
+            f = dims[l + 1]
+            bns.append(dict(weight=f32(1 + 0.1 * r.standard_normal(f)), bias=f32(0.1 * r.standard_normal(f)),
+                            running_mean=f32(0.1 * r.standard_normal(f)),
+                            running_var=f32(0.5 + r.uniform(size=f))))
+        else:
+            bns.append(None)
+    return Ws, bs, bns
+
+
+def encoder_case(in_dim, n, levels=4, codes=256, e=32, bn=False, seed=800):
+    dims = [in_dim] + RUN_SH_LAYERS + [e]
+    Ws, bs, bns = encoder_weights(dims, seed, bn)
+    r = rs(seed + 1 + in_dim + n)
+    x = f32(r.standard_normal((n, in_dim)))
+    return dims, Ws, bs, bns, x
+
+
+def fold_bn(bn, eps=1e-5):
+    """Eval-mode BatchNorm1d as y = t*scale + shift, computed in fp32 the way the product does."""
+    if bn is None:
+        return None, None
+    scale = f32(bn["weight"] / np.sqrt(bn["running_var"] + np.float32(eps)))
+    shift = f32(bn["bias"] - bn["running_mean"] * scale)
+    return scale, shift
+
+
+def state_dict_names(n_layers, bn, levels):
+    """State-dict key layout of the reference RQVAE (checkpoint row)."""
+    step = 4 if bn else 3
+    names = {}
+    for part in ("encoder", "decoder"):
+        names[part] = [f"{part}.mlp_layers.{l * step + 1}" for l in range(n_layers)]
+    names["bn"] = {part: [f"{part}.mlp_layers.{l * step + 2}" for l in range(n_layers - 1)]
+                   for part in ("encoder", "decoder")} if bn else {}
+    names["codebooks"] = [f"rq.vq_layers.{l}.embedding.weight" for l in range(levels)]
+    return names
