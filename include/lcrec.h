@@ -68,19 +68,22 @@ int lcrec_linear_forward(const float *x, int64_t n, int in_dim, const float *W, 
  *   z          device [n][e]         latents
  *   codebooks  device, level l is [K[l]][e] at float offset sum_{m<l} K[m]*e
  *                                    (= torch.cat of rq.get_codebook() rows, rq.py:32-37)
- *   K          host   [L]            codes per level, each a multiple of 32
+ *   K          host   [L]            codes per level (any positive count; a level must fit
+ *                                    in LDS: roundup32(K)*(e+5)*4 bytes <= ~156 KB)
  *   idx_out    device [n][L] int64   (rq.py:54)
- *   xq_out     device [n][e] or NULL sum over levels of the straight-through x_res (rq.py:48)
+ *   xq_out     device [n][e] or NULL sum over levels of the straight-through x_res (rq.py:48);
+ *                                    if xq_accumulate != 0 its current contents are the initial
+ *                                    value of the sum (chaining a run of levels after another)
  *   sse_out    device [L] double or NULL  per-level sum of (c - r)^2; the level loss of
  *                                    vq.py:90-92 is (1+beta)*sse/(n*e)
- *   resid_out  device [L][n][e] or NULL  residual fed into each level (input of
- *                                    lcrec_code_stats)
+ *   resid_out  device [L+1][n][e] or NULL  entry l = residual fed into level l (input of
+ *                                    lcrec_code_stats), entry L = residual after the last level
  *   workspace  device scratch of lcrec_rq_assign_workspace() bytes
  * e must be 16, 32 or 64. */
 size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-                    int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out,
-                    void *workspace, size_t workspace_bytes, void *stream);
+                    int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out,
+                    float *resid_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Encoder MLP + residual quantisation: item embeddings -> index tuples.
  * Replaces RQVAE.get_indices(xs, use_sk=False), index/models/rqvae.py:68-72
@@ -100,6 +103,55 @@ int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers
                         const float *codebooks, const int *K, int L, int64_t *idx_out,
                         float *latent_out, float *xq_out, double *sse_out, void *workspace,
                         size_t workspace_bytes, void *stream);
+
+/* Sinkhorn ("uniform semantic") assignment of one level, for one or many independent
+ * groups of rows.  Replaces the use_sk branch of VectorQuantizer.forward,
+ * index/models/vq.py:76-83: distances (:71-73, same fp32 fma chains as lcrec_rq_assign),
+ * centring on the group's global max/min (:51-61), fp64 sinkhorn_algorithm
+ * (index/models/layers.py:85-108: Q=exp(-d/eps), /total, iters x {/rowsum, /B, /colsum, /K},
+ * *B, every division a true fp64 division in that order) and argmax (:83, first maximum).
+ * Training calls it with one group (the batch, index/trainer.py:114); index generation
+ * with one group per set of colliding items (index/generate_indices.py:113-119), which the
+ * reference runs one forward at a time and this runs as one batched launch.
+ *   resid          device [n][e]   residual entering the level
+ *   codebook       device [K][e]
+ *   group_offsets  HOST  [n_groups+1] ascending row offsets; group g = rows [off[g], off[g+1])
+ *   idx_out        device int64, element i written at idx_out[i*idx_stride]
+ * e must be 16, 32 or 64; K <= 1024 for groups too large for LDS (rows*K > 16384). */
+size_t lcrec_sinkhorn_assign_workspace(int64_t n, int K, const int64_t *group_offsets, int n_groups);
+int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *codebook, int K,
+                          const int64_t *group_offsets, int n_groups, double epsilon, int iters,
+                          int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
+/* Apply a given assignment to one level: gather, squared error, straight-through estimator and
+ * residual update (index/models/vq.py:87-95, index/models/rq.py:47-48) -- what follows the
+ * argmin/argmax inside VectorQuantizer.forward, for levels whose indices came from
+ * lcrec_sinkhorn_assign.
+ *   xq        device [n][e] or NULL: x_q sum, += x_res (starts from 0 unless xq_accumulate)
+ *   resid_out device [n][e] or NULL: residual after the level (may alias resid_in)
+ *   sse_out   device double[1] or NULL; workspace must then hold 8 KB */
+int lcrec_rq_apply_level(const float *resid_in, int64_t n, int e, const float *codebook, int K,
+                         const int64_t *idx, int64_t idx_stride, float *xq, int xq_accumulate,
+                         float *resid_out, double *sse_out, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* Per-code count and sum of the residuals assigned to it:
+ *   count[k] = #{i : idx[i*idx_stride] == k},  sum[k][:] = sum_i resid[i][:]  (item order, fp32).
+ * Replaces the scatter_add_/index_add_ block of index_improve/models/vq.py:151-167 and is the
+ * segmented reduce behind the codebook gradient autograd derives from vq.py:90-92
+ * (dL/dC[k] = w * (count[k]*C[k] - sum[k])).  Bit-identical to the CPU order. */
+int lcrec_code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K,
+                     float *count, float *sum, void *stream);
+
+/* EMA codebook update, index_improve/models/vq.py:155-184, in place:
+ *   ema_count = ema_count*decay + alpha*count;  ema_sum = ema_sum*decay + alpha*sum;
+ *   where ema_count > eps:  codebook = codebook*keep + (ema_sum/(ema_count+eps))*alpha.
+ * decay, alpha = 1-decay and keep = 1-(1-decay) are the reference's python doubles rounded to fp32
+ * by the caller. */
+int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count,
+                     const float *sum, int K, int e, float decay, float alpha, float keep, float eps,
+                     void *stream);
 
 /* Kernel tracing (diagnostic; the reference has no tracing on this path -- its only
  * timing is wall-clock per epoch, index/trainer.py:193-195).  While enabled, every

@@ -28,13 +28,24 @@ _SIGNATURES = {
     "lcrec_rq_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                     ctypes.c_int]),
     "lcrec_rq_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
-                                       ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+                                       ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_encode_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                                         ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "lcrec_encode_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                            ctypes.POINTER(_vp), _vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                            _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_sinkhorn_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int,
+                                                          ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
+    "lcrec_sinkhorn_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int,
+                                             ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_double,
+                                             ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_rq_apply_level": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int, _vp,
+                                            ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_code_stats": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                        _vp, _vp, _vp]),
+    "lcrec_ema_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "lcrec_trace_enable": (ctypes.c_int, [ctypes.c_int]),
     "lcrec_trace_collect": (ctypes.c_int, [_vp, ctypes.c_int]),
 }

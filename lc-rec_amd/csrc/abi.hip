@@ -22,7 +22,8 @@ int fail(int code, const char *fmt, ...)
 }
 
 const char *const kKernelNames[K_COUNT] = {"linear_fwd_128x128", "linear_fwd_128x64", "linear_fwd_128x32",
-                                           "rq_assign", "rq_sse_finalize"};
+                                           "rq_assign", "rq_sse_finalize", "vq_distance", "sinkhorn",
+                                           "sinkhorn_small", "rq_apply_level", "code_stats", "ema_update"};
 
 struct TraceRec { int kernel; hipEvent_t start, stop; };
 static std::mutex g_trace_mu;
@@ -91,10 +92,10 @@ LCREC_API size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L
 }
 
 LCREC_API int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-                              int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out,
-                              void *workspace, size_t workspace_bytes, void *stream)
+                              int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out,
+                              float *resid_out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return rq_assign(z, n, e, codebooks, K, L, idx_out, xq_out, sse_out, resid_out, workspace,
+    return rq_assign(z, n, e, codebooks, K, L, idx_out, xq_out, xq_accumulate, sse_out, resid_out, workspace,
                      workspace_bytes, (hipStream_t)stream);
 }
 
@@ -141,7 +142,7 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
             src = dst;
         }
     }
-    return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, sse_out, nullptr, rq_ws, o.rq_bytes, s);
+    return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, 0, sse_out, nullptr, rq_ws, o.rq_bytes, s);
 }
 
 LCREC_API int lcrec_trace_enable(int on)
@@ -174,4 +175,41 @@ LCREC_API int lcrec_trace_collect(lcrec_trace_entry *out, int capacity)
     for (int k = 0; k < K_COUNT && n < capacity; ++k)
         if (launches[k]) { out[n].kernel = kKernelNames[k]; out[n].launches = launches[k]; out[n].total_ms = ms[k]; ++n; }
     return n;
+}
+
+LCREC_API size_t lcrec_sinkhorn_assign_workspace(int64_t n, int K, const int64_t *group_offsets, int n_groups)
+{
+    if (!group_offsets || n_groups < 1) return 256;
+    return sinkhorn_workspace(n, K, group_offsets, n_groups);
+}
+
+LCREC_API int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *codebook, int K,
+                                    const int64_t *group_offsets, int n_groups, double epsilon, int iters,
+                                    int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    return sinkhorn_assign(resid, n, e, codebook, K, group_offsets, n_groups, epsilon, iters, idx_out, idx_stride,
+                           workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_rq_apply_level(const float *resid_in, int64_t n, int e, const float *codebook, int K,
+                                   const int64_t *idx, int64_t idx_stride, float *xq, int xq_accumulate,
+                                   float *resid_out, double *sse_out, void *workspace, size_t workspace_bytes,
+                                   void *stream)
+{
+    return apply_level(resid_in, n, e, codebook, K, idx, idx_stride, xq, xq_accumulate, resid_out, sse_out, workspace,
+                       workspace_bytes, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K,
+                               float *count, float *sum, void *stream)
+{
+    return code_stats(idx, idx_stride, resid, n, e, K, count, sum, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count,
+                               const float *sum, int K, int e, float decay, float alpha, float keep, float eps,
+                               void *stream)
+{
+    return ema_update(ema_count, ema_sum, codebook, count, sum, K, e, decay, alpha, keep, eps, (hipStream_t)stream);
 }

@@ -27,7 +27,8 @@ inline int check_launch(const char *what)
 }
 
 // Kernel ids for lcrec_trace_*.
-enum KernelId { K_LINEAR_128x128 = 0, K_LINEAR_128x64, K_LINEAR_128x32, K_RQ_ASSIGN, K_RQ_SSE_FINALIZE, K_COUNT };
+enum KernelId { K_LINEAR_128x128 = 0, K_LINEAR_128x64, K_LINEAR_128x32, K_RQ_ASSIGN, K_RQ_SSE_FINALIZE,
+                K_VQ_DISTANCE, K_SINKHORN, K_SINKHORN_SMALL, K_APPLY_LEVEL, K_CODE_STATS, K_EMA_UPDATE, K_COUNT };
 extern const char *const kKernelNames[K_COUNT];
 bool trace_on();
 void trace_begin(int kernel, hipStream_t stream);
@@ -50,7 +51,19 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
 
 size_t rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-              int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out, void *workspace,
-              size_t workspace_bytes, hipStream_t stream);
+              int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
+              void *workspace, size_t workspace_bytes, hipStream_t stream);
+
+size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G);
+int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
+                    int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
+                    hipStream_t stream);
+int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, const int64_t *idx, int64_t idx_stride,
+                float *xq, int xq_accumulate, float *r_out, double *sse_out, void *workspace, size_t workspace_bytes,
+                hipStream_t stream);
+int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
+               float *sum, hipStream_t stream);
+int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,
+               float decay, float alpha, float keep, float eps, hipStream_t stream);
 
 }  // namespace lcrec

@@ -34,16 +34,18 @@ namespace lcrec {
 
 struct RqParams {
     const float *z_in;     // [n][E] residual entering level l0
-    const float *cb;       // codebook rows of levels l0..l1-1, contiguous [rows][E]
+    const float *cb;       // all codebooks (level l starts at float offset cb_off[l])
     int64_t n;
     int l0, l1, L;
     int K[LCREC_MAX_LEVELS];        // codes per level (absolute level index)
-    int row_off[LCREC_MAX_LEVELS];  // first LDS row of a level (absolute level index)
-    int rows;                       // total rows staged by this launch
+    int64_t cb_off[LCREC_MAX_LEVELS];  // float offset of a level's [K][E] rows in cb
+    int row_off[LCREC_MAX_LEVELS];  // first LDS row of a level; a level occupies K rounded up to 32 rows
+    int rows;                       // total (padded) rows staged by this launch
+    int xq_accumulate;              // xq holds an initial value to add to (else starts at 0)
     int64_t *idx_out;      // [n][L]
     float *xq;             // [n][E] in/out (read when l0 > 0), or NULL
     float *resid_next;     // [n][E] residual after level l1-1, or NULL
-    float *resid_levels;   // [L][n][E] residual entering each level, or NULL
+    float *resid_levels;   // [L+1][n][E]: entry l = residual entering level l, entry L = final residual; or NULL
     double *sse_partial;   // [gridDim.x][L], or NULL
 };
 
@@ -71,14 +73,24 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
     const int h = lane >> 5, c = lane & 31;
 
     // ---- stage codebooks: global [row][E] -> LDS [row][even k | odd k | pad]
-    for (int q = tid; q < p.rows * (E / 8); q += THREADS) {
-        const int row = q / (E / 8), g = q % (E / 8);
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.cb + (size_t)row * E + g * 8);
-        const f32x4 a = src[0], b = src[1];
+    // (rows K..roundup32(K) of a level are padding: zero vector, norm +inf, never the argmin)
+    for (int l = p.l0; l < p.l1; ++l) {
+      const int kpad = (p.K[l] + 31) & ~31;
+      const float *lsrc = p.cb + p.cb_off[l];
+      for (int q = tid; q < kpad * (E / 8); q += THREADS) {
+        const int lrow = q / (E / 8), g = q % (E / 8);
+        const int row = p.row_off[l] + lrow;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+        if (lrow < p.K[l]) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(lsrc + (size_t)lrow * E + g * 8);
+            a = src[0];
+            b = src[1];
+        }
         f32x4 ev = {a[0], a[2], b[0], b[2]};
         f32x4 od = {a[1], a[3], b[1], b[3]};
         *reinterpret_cast<f32x4 *>(cbs + row * S + g * 4) = ev;
         *reinterpret_cast<f32x4 *>(cbs + row * S + H + g * 4) = od;
+      }
     }
     for (int q = tid; q < WAVES * p.L; q += THREADS) wave_sse[q] = 0.0;
     __syncthreads();
@@ -92,6 +104,10 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
         }
         ccs[row] = a;
     }
+    __syncthreads();
+    for (int l = p.l0; l < p.l1; ++l)   // padding rows
+        for (int row = p.row_off[l] + p.K[l] + tid; row < p.row_off[l] + ((p.K[l] + 31) & ~31); row += THREADS)
+            ccs[row] = __builtin_inff();
     __syncthreads();
 
     const int64_t tiles = (p.n + 63) / 64;
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             for (int k = 0; k < E; ++k) r[k] = 0.f;
         }
         if (WANT_XQ) {
-            if (p.l0 > 0 && valid) {
+            if ((p.l0 > 0 || p.xq_accumulate) && valid) {
                 const f32x4 *src = reinterpret_cast<const f32x4 *>(p.xq + item * E);
 #pragma unroll
                 for (int q = 0; q < E / 4; ++q) {
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
 
         for (int l = p.l0; l < p.l1; ++l) {
             const int ro = p.row_off[l];
-            const int nblk = p.K[l] >> 5;
+            const int nblk = (p.K[l] + 31) >> 5;
 
             if (p.resid_levels && valid) {
                 f32x4 *dst = reinterpret_cast<f32x4 *>(p.resid_levels + ((size_t)l * p.n + item) * E);
@@ -252,6 +268,14 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
                     dst[q] = v;
                 }
             }
+            if (p.resid_levels && p.l1 == p.L) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(p.resid_levels + ((size_t)p.L * p.n + item) * E);
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    f32x4 v = {r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+                    dst[q] = v;
+                }
+            }
         }
     }
 
@@ -332,8 +356,8 @@ static int dispatch(const RqParams &p, int threads, int grid, size_t lds, bool w
 }
 
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-              int64_t *idx_out, float *xq_out, double *sse_out, float *resid_out, void *workspace,
-              size_t workspace_bytes, hipStream_t stream)
+              int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
+              void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     if (!z || !codebooks || !K || !idx_out) return fail(LCREC_EINVAL, "rq_assign: NULL pointer");
     if (n < 0 || L < 1 || L > LCREC_MAX_LEVELS) return fail(LCREC_EINVAL, "rq_assign: bad n=%lld or L=%d", (long long)n, L);
@@ -343,8 +367,8 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     const int threads = threads_for(e, n);
     const int waves = threads / 64;
     for (int l = 0; l < L; ++l) {
-        if (K[l] <= 0 || K[l] % 32) return fail(LCREC_EUNSUPPORTED, "rq_assign: K[%d]=%d is not a positive multiple of 32", l, K[l]);
-        if (lds_bytes(K[l], e, L, waves) > LDS_BUDGET)
+        if (K[l] <= 0) return fail(LCREC_EINVAL, "rq_assign: K[%d]=%d", l, K[l]);
+        if (lds_bytes((K[l] + 31) & ~31, e, L, waves) > LDS_BUDGET)
             return fail(LCREC_EUNSUPPORTED, "rq_assign: level %d (K=%d, e=%d) does not fit in 160 KB of LDS", l, K[l], e);
     }
     if (n == 0) return LCREC_OK;
@@ -358,20 +382,25 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     const int grid = grid_for(n, threads);
 
     // Greedily pack consecutive levels into launches whose codebooks fit in LDS.
-    int64_t cb_off = 0;
+    int64_t cb_offs[LCREC_MAX_LEVELS];
+    {
+        int64_t o = 0;
+        for (int l = 0; l < L; ++l) { cb_offs[l] = o; o += (int64_t)K[l] * e; }
+    }
     const float *zin = z;
     int l0 = 0;
     while (l0 < L) {
         RqParams p = {};
         int rows = 0, l1 = l0;
-        while (l1 < L && lds_bytes(rows + K[l1], e, L, waves) <= LDS_BUDGET) {
+        while (l1 < L && lds_bytes(rows + ((K[l1] + 31) & ~31), e, L, waves) <= LDS_BUDGET) {
             p.row_off[l1] = rows;
-            rows += K[l1];
+            rows += (K[l1] + 31) & ~31;
             ++l1;
         }
-        for (int l = 0; l < L; ++l) p.K[l] = K[l];
+        for (int l = 0; l < L; ++l) { p.K[l] = K[l]; p.cb_off[l] = cb_offs[l]; }
+        p.xq_accumulate = xq_accumulate;
         p.z_in = zin;
-        p.cb = codebooks + cb_off;
+        p.cb = codebooks;
         p.n = n; p.l0 = l0; p.l1 = l1; p.L = L; p.rows = rows;
         p.idx_out = idx_out;
         p.xq = xq_out;
@@ -392,7 +421,6 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
             rc = check_launch("rq_sse_finalize_kernel");
             if (rc) return rc;
         }
-        for (int l = l0; l < l1; ++l) cb_off += (int64_t)K[l] * e;
         zin = next;
         l0 = l1;
     }

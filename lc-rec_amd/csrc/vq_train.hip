@@ -1,0 +1,695 @@
+// Quantiser kernels around the hard-assignment path: Sinkhorn ("uniform semantic")
+// assignment, applying a given assignment to a level, the per-code segmented reduce
+// that feeds the codebook gradient and the EMA update, and the EMA blend itself.
+//
+// Reference (paths relative to the reference root):
+//   index/models/vq.py:51-61,76-83       centring + fp64 Sinkhorn + argmax
+//   index/models/layers.py:85-108        sinkhorn_algorithm
+//   index/models/vq.py:87-95, rq.py:47-48  gather, losses, STE, residual update
+//   index_improve/models/vq.py:151-184   count / per-code sum / EMA / blend
+//   autograd of vq.py:90-92: dL/dC[k] ~ n_k*C[k] - S_k
+#include "common.h"
+
+#include <vector>
+
+namespace lcrec {
+
+// ------------------------------------------------------------------------------------------
+// Distances d[i][j] = (xx_i + cc_j) - 2*dot_ij, fp32, same fma chains as the argmin kernel
+// (vq.py:71-73).  One thread owns one code (its row in registers) and walks the item tile.
+// ------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void load_code_row(const float *cb, int K, int j, float (&c)[E], float &cc)
+{
+    cc = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) c[k] = 0.f;
+    if (j < K) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(cb + (size_t)j * E);
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const f32x4 v = src[q];
+            c[4 * q] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) cc = __builtin_fmaf(c[k], c[k], cc);
+    }
+}
+
+// order-preserving float <-> uint map for atomic min/max
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+constexpr int DIST_ITEMS = 32;   // items per block in the distance kernel
+
+// grid = (ceil(n/DIST_ITEMS), ceil(K/256)); d is [n][K]; minmax = {ord(min), ord(max)} zero/one-initialised
+template <int E>
+__global__ __launch_bounds__(256) void vq_distance_kernel(const float *__restrict__ r, int64_t n,
+                                                         const float *__restrict__ cb, int K,
+                                                         float *__restrict__ d, unsigned *minmax)
+{
+    __shared__ float rs[DIST_ITEMS][E];
+    __shared__ float xs[DIST_ITEMS];
+    __shared__ unsigned red[2][4];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * DIST_ITEMS;
+    const int j = blockIdx.y * 256 + tid;
+    float c[E], cc;
+    load_code_row<E>(cb, K, j, c, cc);
+    for (int q = tid; q < DIST_ITEMS * E; q += 256) {
+        const int64_t i = i0 + q / E;
+        rs[q / E][q % E] = i < n ? r[i * E + q % E] : 0.f;
+    }
+    __syncthreads();
+    if (tid < DIST_ITEMS) {
+        float xx = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) xx = __builtin_fmaf(rs[tid][k], rs[tid][k], xx);
+        xs[tid] = xx;
+    }
+    __syncthreads();
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int t = 0; t < DIST_ITEMS; ++t) {
+        const int64_t i = i0 + t;
+        if (i >= n) break;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) dot = __builtin_fmaf(rs[t][k], c[k], dot);
+        const float s = xs[t] + cc;
+        const float dv = __builtin_fmaf(-2.0f, dot, s);
+        if (j < K) {
+            d[i * K + j] = dv;
+            lo = dv < lo ? dv : lo;
+            hi = dv > hi ? dv : hi;
+        }
+    }
+    if (minmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = f2ord(lo); red[1][tid >> 6] = f2ord(hi); }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned a = red[0][0], b = red[1][0];
+            for (int w = 1; w < 4; ++w) { a = red[0][w] < a ? red[0][w] : a; b = red[1][w] > b ? red[1][w] : b; }
+            atomicMin(&minmax[0], a);
+            atomicMax(&minmax[1], b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Sinkhorn, large problem (one B x K matrix, training): Q lives in global memory (L2-resident
+// at 2048 x 256 x 8 B = 4 MB); one launch per iteration.  A block owns SK_ROWS whole rows, so
+// row sums are block-local; column sums travel between launches as per-block partials.
+//   launch 0      : Q = exp(-centre(d)/eps), per-block partial of the grand total
+//   launch t (1..iters): [t==1: Q /= total | t>1: Q /= colsum, Q /= K]; Q /= rowsum; Q /= B; emit column partials
+//   final         : Q /= colsum; Q /= K; Q *= B; argmax per row (first maximum)
+// ------------------------------------------------------------------------------------------
+constexpr int SK_ROWS = 32;      // rows per block
+constexpr int SK_THREADS = 512;  // 8 waves, 4 rows each
+constexpr int SK_MAXC = 16;      // columns per lane: K <= 1024
+
+struct SkBig {
+    const float *d;       // [B][K]
+    double *Q;            // [B][K]
+    double *col_part;     // [2][nblk][K] ping-pong column partial sums
+    double *tot_part;     // [nblk]
+    const unsigned *minmax;
+    int64_t B;
+    int K, nblk;
+    double eps;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(SK_THREADS) void sk_init_kernel(SkBig p)
+{
+    __shared__ double wsum[SK_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // vq.py:52-60 in fp32: middle = (max+min)/2; amplitude = max - middle + 1e-5
+    const float hi = ord2f(p.minmax[1]), lo = ord2f(p.minmax[0]);
+    const float middle = (hi + lo) / 2.0f;
+    const float amplitude = (hi - middle) + 1e-5f;
+    double part = 0.0;
+    for (int rr = wave; rr < SK_ROWS; rr += SK_THREADS / 64) {
+        const int64_t row = (int64_t)blockIdx.x * SK_ROWS + rr;
+        if (row >= p.B) break;
+        for (int j = lane; j < p.K; j += 64) {
+            const float cen = (p.d[row * p.K + j] - middle) / amplitude;
+            const double q = exp(-(double)cen / p.eps);
+            p.Q[row * p.K + j] = q;
+            part += q;
+        }
+    }
+    part = wave_sum(part);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < SK_THREADS / 64; ++w) s += wsum[w];
+        p.tot_part[blockIdx.x] = s;
+    }
+}
+
+// mode 0: first iteration (divide by the grand total first); mode 1: later iteration (column-normalise first)
+__global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(SkBig p, int mode, int src)
+{
+    extern __shared__ __attribute__((aligned(16))) double sk_sm[];
+    double *colsum = sk_sm;                 // [K]   (mode 1)
+    double *colacc = sk_sm + p.K;           // [waves][K] partials of this block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WAVES = SK_THREADS / 64;
+    double total = 0.0;
+    if (mode == 0) {
+        for (int b = 0; b < p.nblk; ++b) total += p.tot_part[b];
+    } else {
+        const double *cp = p.col_part + (size_t)src * p.nblk * p.K;
+        for (int j = threadIdx.x; j < p.K; j += SK_THREADS) {
+            double s = 0.0;
+            for (int b = 0; b < p.nblk; ++b) s += cp[(size_t)b * p.K + j];
+            colsum[j] = s;
+        }
+        __syncthreads();
+    }
+    double acc[SK_MAXC];
+#pragma unroll
+    for (int c = 0; c < SK_MAXC; ++c) acc[c] = 0.0;
+    const double Bd = (double)p.B, Kd = (double)p.K;
+    for (int rr = wave; rr < SK_ROWS; rr += WAVES) {
+        const int64_t row = (int64_t)blockIdx.x * SK_ROWS + rr;
+        if (row >= p.B) break;
+        double q[SK_MAXC];
+        double rs = 0.0;
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            q[c] = 0.0;
+            if (j < p.K) {
+                double v = p.Q[row * p.K + j];
+                if (mode == 0) v = v / total;
+                else { v = v / colsum[j]; v = v / Kd; }
+                q[c] = v;
+                rs += v;
+            }
+        }
+        rs = wave_sum(rs);
+#pragma unroll
+        for (int c = 0; c < SK_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            if (j < p.K) {
+                double v = q[c] / rs;
+                v = v / Bd;
+                p.Q[row * p.K + j] = v;
+                acc[c] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < SK_MAXC; ++c) {
+        const int j = lane + 64 * c;
+        if (j < p.K) colacc[wave * p.K + j] = acc[c];
+    }
+    __syncthreads();
+    double *out = p.col_part + ((size_t)(src ^ 1) * p.nblk + blockIdx.x) * p.K;
+    for (int j = threadIdx.x; j < p.K; j += SK_THREADS) {
+        double s = 0.0;
+        for (int w = 0; w < WAVES; ++w) s += colacc[w * p.K + j];
+        out[j] = s;
+    }
+}
+
+__global__ __launch_bounds__(SK_THREADS) void sk_final_kernel(SkBig p, int src, int64_t *idx_out, int64_t idx_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double sk_sm[];
+    double *colsum = sk_sm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *cp = p.col_part + (size_t)src * p.nblk * p.K;
+    for (int j = threadIdx.x; j < p.K; j += SK_THREADS) {
+        double s = 0.0;
+        for (int b = 0; b < p.nblk; ++b) s += cp[(size_t)b * p.K + j];
+        colsum[j] = s;
+    }
+    __syncthreads();
+    const double Bd = (double)p.B, Kd = (double)p.K;
+    for (int rr = wave; rr < SK_ROWS; rr += SK_THREADS / 64) {
+        const int64_t row = (int64_t)blockIdx.x * SK_ROWS + rr;
+        if (row >= p.B) break;
+        double best = -1.0;
+        int bj = 0;
+        for (int j = lane; j < p.K; j += 64) {
+            double v = p.Q[row * p.K + j] / colsum[j];
+            v = v / Kd;
+            v = v * Bd;
+            if (v > best) { best = v; bj = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double b2 = __shfl_xor(best, o, 64);
+            const int j2 = __shfl_xor(bj, o, 64);
+            if (b2 > best || (b2 == best && j2 < bj)) { best = b2; bj = j2; }
+        }
+        if (lane == 0) idx_out[row * idx_stride] = bj;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Sinkhorn, many small independent problems (collision groups of generate_indices.py:113-119):
+// one workgroup per group, the whole g x K matrix in LDS (g*K <= SKS_MAX doubles).
+// ------------------------------------------------------------------------------------------
+constexpr int SKS_MAX = 16384;   // doubles of LDS for Q (128 KB)
+constexpr int SKS_THREADS = 256;
+
+__device__ __forceinline__ double block_sum(double v, double *scratch)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < SKS_THREADS / 64; ++w) s += scratch[w];
+    return s;
+}
+
+template <int E>
+__global__ __launch_bounds__(SKS_THREADS) void sk_small_kernel(const float *__restrict__ r, const float *__restrict__ cb,
+                                                              int K, const int64_t *__restrict__ offs,
+                                                              double eps, int iters, int64_t *idx_out,
+                                                              int64_t idx_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double sks_sm[];
+    __shared__ double scratch[SKS_THREADS / 64];
+    __shared__ float fred[2][SKS_THREADS / 64];
+    const int64_t i0 = offs[2 * blockIdx.x];           // offs holds (begin, end) pairs
+    const int g = (int)(offs[2 * blockIdx.x + 1] - i0);
+    if (g <= 0) return;
+    double *Q = sks_sm;                          // [g][K]
+    double *rsum = Q + (size_t)g * K;            // [g]
+    double *csum = rsum + ((g + 1) & ~1);        // [K]
+    float *dmat = reinterpret_cast<float *>(Q);  // fp32 distances alias the front half of Q first
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // distances, fp32 canonical chains; thread j owns code j (+256, ...)
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int j = tid; j < K; j += SKS_THREADS) {
+        float c[E], cc;
+        load_code_row<E>(cb, K, j, c, cc);
+        for (int t = 0; t < g; ++t) {
+            const float *ri = r + (i0 + t) * E;
+            float xx = 0.f, dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < E; ++k) xx = __builtin_fmaf(ri[k], ri[k], xx);
+#pragma unroll
+            for (int k = 0; k < E; ++k) dot = __builtin_fmaf(ri[k], c[k], dot);
+            const float dv = __builtin_fmaf(-2.0f, dot, xx + cc);
+            dmat[(size_t)t * K + j] = dv;
+            lo = dv < lo ? dv : lo;
+            hi = dv > hi ? dv : hi;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0) { fred[0][wave] = lo; fred[1][wave] = hi; }
+    __syncthreads();
+    for (int w = 0; w < SKS_THREADS / 64; ++w) { lo = fred[0][w] < lo ? fred[0][w] : lo; hi = fred[1][w] > hi ? fred[1][w] : hi; }
+    const float middle = (hi + lo) / 2.0f;
+    const float amplitude = (hi - middle) + 1e-5f;
+
+    // Q = exp(-centre(d)/eps): walk backwards so the fp64 store never overtakes an unread fp32 slot
+    const int total_el = g * K;
+    double part = 0.0;
+    {
+        // each thread converts a contiguous chunk, highest chunk first is not needed: read all into registers per pass
+        // pass structure: chunks of SKS_THREADS elements from the END; element q (fp32 at byte 4q) -> fp64 at byte 8q >= 4q
+        for (int base = ((total_el - 1) / SKS_THREADS) * SKS_THREADS; base >= 0; base -= SKS_THREADS) {
+            const int q = base + tid;
+            float dv = 0.f;
+            if (q < total_el) dv = dmat[q];
+            __syncthreads();
+            if (q < total_el) {
+                const float cen = (dv - middle) / amplitude;
+                const double v = exp(-(double)cen / eps);
+                Q[q] = v;
+                part += v;
+            }
+            __syncthreads();
+        }
+    }
+    const double total = block_sum(part, scratch);
+    for (int q = tid; q < total_el; q += SKS_THREADS) Q[q] = Q[q] / total;
+    __syncthreads();
+    const double Bd = (double)g, Kd = (double)K;
+    for (int it = 0; it < iters; ++it) {
+        for (int t = wave; t < g; t += SKS_THREADS / 64) {          // row sums (layers.py:99)
+            double s = 0.0;
+            for (int j = lane; j < K; j += 64) s += Q[(size_t)t * K + j];
+            s = wave_sum(s);
+            if (lane == 0) rsum[t] = s;
+        }
+        __syncthreads();
+        for (int j = tid; j < K; j += SKS_THREADS) {                 // Q /= rowsum; Q /= B; column sums (:100-103)
+            double s = 0.0;
+            for (int t = 0; t < g; ++t) {
+                double v = Q[(size_t)t * K + j] / rsum[t];
+                v = v / Bd;
+                Q[(size_t)t * K + j] = v;
+                s += v;
+            }
+            csum[j] = s;
+            for (int t = 0; t < g; ++t) {                            // Q /= colsum; Q /= K (:103-104)
+                double v = Q[(size_t)t * K + j] / s;
+                Q[(size_t)t * K + j] = v / Kd;
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = wave; t < g; t += SKS_THREADS / 64) {               // Q *= B; argmax (:107, vq.py:83)
+        double best = -1.0;
+        int bj = 0;
+        for (int j = lane; j < K; j += 64) {
+            const double v = Q[(size_t)t * K + j] * Bd;
+            if (v > best) { best = v; bj = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double b2 = __shfl_xor(best, o, 64);
+            const int j2 = __shfl_xor(bj, o, 64);
+            if (b2 > best || (b2 == best && j2 < bj)) { best = b2; bj = j2; }
+        }
+        if (lane == 0) idx_out[(i0 + t) * idx_stride] = bj;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Apply a given assignment to one level (vq.py:87-95 + rq.py:47-48): gather, SSE, STE, residual.
+// One wave-quarter per item: thread handles 4 consecutive dims.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apply_level_kernel(const float *__restrict__ r_in, int64_t n, int e,
+                                                         const float *__restrict__ cb, int K,
+                                                         const int64_t *__restrict__ idx, int64_t idx_stride,
+                                                         float *xq, int xq_accumulate, float *r_out,
+                                                         double *sse_partial)
+{
+    __shared__ double wsum[4];
+    const int per = e / 4;
+    const int64_t total = n * per;
+    double part = 0.0;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t i = q / per;
+        const int k4 = (int)(q % per) * 4;
+        int64_t j = idx[i * idx_stride];
+        j = j < 0 ? 0 : (j >= K ? K - 1 : j);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(cb + j * e + k4);
+        const f32x4 r = *reinterpret_cast<const f32x4 *>(r_in + i * e + k4);
+        f32x4 xo = {0.f, 0.f, 0.f, 0.f}, ro;
+        if (xq && xq_accumulate) xo = *reinterpret_cast<const f32x4 *>(xq + i * e + k4);
+        float sse = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float tt = c[t] - r[t];
+            sse = __builtin_fmaf(tt, tt, sse);
+            const float s = r[t] + tt;
+            xo[t] = xo[t] + s;
+            ro[t] = r[t] - s;
+        }
+        part += (double)sse;
+        if (xq) *reinterpret_cast<f32x4 *>(xq + i * e + k4) = xo;
+        if (r_out) *reinterpret_cast<f32x4 *>(r_out + i * e + k4) = ro;
+    }
+    if (sse_partial) {
+        part = wave_sum(part);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) sse_partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
+__global__ void sum_partials_kernel(const double *partial, int count, double *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < count; ++b) s += partial[b];
+        *out = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-code statistics: count[k] = #{i: idx_i = k}, sum[k][:] = sum of resid_i over those items,
+// added in ITEM ORDER in fp32 -- the order of the CPU index_add_ the reference's EMA path uses
+// (index_improve/models/vq.py:151-167), so the result is bit-identical to the CPU and
+// independent of launch geometry.  Thread (code, dim) scans all items; items stream through LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int CS_CHUNK = 256;
+
+template <int E>
+__global__ __launch_bounds__(256) void code_stats_kernel(const int64_t *__restrict__ idx, int64_t idx_stride,
+                                                        const float *__restrict__ resid, int64_t n, int K,
+                                                        float *__restrict__ count, float *__restrict__ sum)
+{
+    constexpr int CODES = 256 / E;
+    __shared__ int sidx[CS_CHUNK];
+    __shared__ float sres[CS_CHUNK][E];
+    const int tid = threadIdx.x;
+    const int d = tid % E;
+    const int k = blockIdx.x * CODES + tid / E;
+    float acc = 0.f, cnt = 0.f;
+    for (int64_t i0 = 0; i0 < n; i0 += CS_CHUNK) {
+        const int m = (int)((n - i0 < CS_CHUNK) ? n - i0 : CS_CHUNK);
+        __syncthreads();
+        for (int q = tid; q < m; q += 256) sidx[q] = (int)idx[(i0 + q) * idx_stride];
+        for (int q = tid; q < m * E; q += 256) sres[q / E][q % E] = resid[i0 * E + q];
+        __syncthreads();
+        for (int t = 0; t < m; ++t) {
+            if (sidx[t] == k) {
+                acc = acc + sres[t][d];
+                cnt = cnt + 1.0f;
+            }
+        }
+    }
+    if (k < K) {
+        sum[(size_t)k * E + d] = acc;
+        if (d == 0) count[k] = cnt;
+    }
+}
+
+// index_improve/models/vq.py:155-184.  decay/alpha/keep are the reference's python-double rates
+// rounded to fp32 by the caller (alpha = 1-decay, keep = 1-(1-decay)).
+__global__ void ema_update_kernel(float *ema_count, float *ema_sum, float *codebook, const float *count,
+                                  const float *sum, int K, int e, float decay, float alpha, float keep, float eps)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)K * e) return;
+    const int k = (int)(q / e);
+    const float en = __builtin_fmaf(count[k], alpha, ema_count[k] * decay);
+    const float ew = __builtin_fmaf(sum[q], alpha, ema_sum[q] * decay);
+    ema_sum[q] = ew;
+    if (en > eps) {
+        const float nw = ew / (en + eps);
+        const float a = codebook[q] * keep;
+        const float b = nw * alpha;
+        codebook[q] = a + b;
+    }
+    // the e threads of a code sit in one wavefront (64 % e == 0), so every lane has read
+    // ema_count[k] above before lane d==0 overwrites it here
+    if (q % e == 0) ema_count[k] = en;
+}
+
+// ---------------------------------------------------------------- host launchers
+
+int vq_distances(const float *r, int64_t n, int e, const float *cb, int K, float *d, unsigned *minmax,
+                 hipStream_t stream)
+{
+    dim3 grid((unsigned)((n + DIST_ITEMS - 1) / DIST_ITEMS), (unsigned)((K + 255) / 256));
+    TraceScope trace(K_VQ_DISTANCE, stream);
+    if (e == 16) hipLaunchKernelGGL(vq_distance_kernel<16>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax);
+    else if (e == 32) hipLaunchKernelGGL(vq_distance_kernel<32>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax);
+    else if (e == 64) hipLaunchKernelGGL(vq_distance_kernel<64>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax);
+    else return fail(LCREC_EUNSUPPORTED, "vq_distances: e_dim=%d (supported: 16, 32, 64)", e);
+    return check_launch("vq_distance_kernel");
+}
+
+static size_t sk_big_bytes(int64_t B, int K)
+{
+    const int64_t nblk = (B + SK_ROWS - 1) / SK_ROWS;
+    return align_up((size_t)B * K * sizeof(float), 256) + align_up((size_t)B * K * sizeof(double), 256) +
+           align_up((size_t)2 * nblk * K * sizeof(double), 256) + align_up((size_t)nblk * sizeof(double), 256) + 256;
+}
+
+size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G)
+{
+    int64_t biggest = 0;
+    for (int g = 0; g < G; ++g) {
+        const int64_t sz = offs[g + 1] - offs[g];
+        if (sz * K > SKS_MAX && sz > biggest) biggest = sz;
+    }
+    (void)n;
+    return align_up((size_t)2 * G * sizeof(int64_t), 256) + (biggest ? sk_big_bytes(biggest, K) : 0);
+}
+
+static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K, double eps, int iters,
+                        int64_t *idx_out, int64_t idx_stride, char *ws, hipStream_t stream)
+{
+    if (K > 64 * SK_MAXC) return fail(LCREC_EUNSUPPORTED, "sinkhorn: K=%d > %d", K, 64 * SK_MAXC);
+    SkBig p;
+    const int64_t nblk = (B + SK_ROWS - 1) / SK_ROWS;
+    float *d = reinterpret_cast<float *>(ws);
+    ws += align_up((size_t)B * K * sizeof(float), 256);
+    p.Q = reinterpret_cast<double *>(ws);
+    ws += align_up((size_t)B * K * sizeof(double), 256);
+    p.col_part = reinterpret_cast<double *>(ws);
+    ws += align_up((size_t)2 * nblk * K * sizeof(double), 256);
+    p.tot_part = reinterpret_cast<double *>(ws);
+    ws += align_up((size_t)nblk * sizeof(double), 256);
+    unsigned *minmax = reinterpret_cast<unsigned *>(ws);
+    p.d = d; p.minmax = minmax; p.B = B; p.K = K; p.nblk = (int)nblk; p.eps = eps;
+    const unsigned init[2] = {0xffffffffu, 0u};
+    hipError_t he = hipMemcpyAsync(minmax, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn: %s", hipGetErrorString(he));
+    int rc = vq_distances(r, B, e, cb, K, d, minmax, stream);
+    if (rc) return rc;
+    TraceScope trace(K_SINKHORN, stream);
+    hipLaunchKernelGGL(sk_init_kernel, dim3((unsigned)nblk), dim3(SK_THREADS), 0, stream, p);
+    const size_t lds_iter = (size_t)(1 + SK_THREADS / 64) * K * sizeof(double);
+    int src = 0;
+    for (int t = 0; t < iters; ++t) {
+        hipLaunchKernelGGL(sk_iter_kernel, dim3((unsigned)nblk), dim3(SK_THREADS), lds_iter, stream, p, t == 0 ? 0 : 1, src);
+        src ^= 1;
+    }
+    if (iters == 0) return fail(LCREC_EUNSUPPORTED, "sinkhorn: iters must be >= 1");
+    hipLaunchKernelGGL(sk_final_kernel, dim3((unsigned)nblk), dim3(SK_THREADS), (size_t)K * sizeof(double), stream, p, src,
+                       idx_out, idx_stride);
+    return check_launch("sinkhorn kernels");
+}
+
+template <int E>
+static int launch_sk_small(const float *r, const float *cb, int K, const int64_t *offs_dev, int G, int maxg, double eps,
+                           int iters, int64_t *idx_out, int64_t idx_stride, hipStream_t stream)
+{
+    const size_t lds = ((size_t)maxg * K + ((maxg + 1) & ~1) + K) * sizeof(double);
+    auto kern = sk_small_kernel<E>;
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(he));
+    TraceScope trace(K_SINKHORN_SMALL, stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(SKS_THREADS), lds, stream, r, cb, K, offs_dev, eps, iters, idx_out,
+                       idx_stride);
+    return check_launch("sk_small_kernel");
+}
+
+int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
+                    int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
+                    hipStream_t stream)
+{
+    if (!r || !cb || !offs || !idx_out) return fail(LCREC_EINVAL, "sinkhorn_assign: NULL pointer");
+    if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "sinkhorn_assign: e_dim=%d (supported: 16, 32, 64)", e);
+    if (G < 0 || K < 1 || iters < 1 || !(eps > 0)) return fail(LCREC_EINVAL, "sinkhorn_assign: bad G/K/iters/eps");
+    if (G == 0) return LCREC_OK;
+    if (offs[0] < 0 || offs[G] > n) return fail(LCREC_EINVAL, "sinkhorn_assign: group offsets outside [0, n]");
+    for (int g = 0; g < G; ++g)
+        if (offs[g + 1] < offs[g]) return fail(LCREC_EINVAL, "sinkhorn_assign: group offsets not ascending");
+    const size_t need = sinkhorn_workspace(n, K, offs, G);
+    if (!workspace || workspace_bytes < need)
+        return fail(LCREC_EWORKSPACE, "sinkhorn_assign: workspace %zu B < required %zu B", workspace_bytes, need);
+    char *ws = reinterpret_cast<char *>(workspace);
+    int64_t *pairs_dev = reinterpret_cast<int64_t *>(ws);
+    ws += align_up((size_t)2 * G * sizeof(int64_t), 256);
+
+    // groups whose g x K matrix fits in LDS run together, one workgroup each
+    std::vector<int64_t> pairs;
+    int maxg = 0;
+    for (int g = 0; g < G; ++g) {
+        const int64_t sz = offs[g + 1] - offs[g];
+        if (sz > 0 && sz * K <= SKS_MAX) {
+            pairs.push_back(offs[g]);
+            pairs.push_back(offs[g + 1]);
+            if (sz > maxg) maxg = (int)sz;
+        }
+    }
+    if (!pairs.empty()) {
+        hipError_t he = hipMemcpyAsync(pairs_dev, pairs.data(), sizeof(int64_t) * pairs.size(), hipMemcpyHostToDevice, stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(stream);   // pairs is a host temporary
+        if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn_assign: %s", hipGetErrorString(he));
+        const int nb = (int)(pairs.size() / 2);
+        int rc;
+        if (e == 16) rc = launch_sk_small<16>(r, cb, K, pairs_dev, nb, maxg, eps, iters, idx_out, idx_stride, stream);
+        else if (e == 32) rc = launch_sk_small<32>(r, cb, K, pairs_dev, nb, maxg, eps, iters, idx_out, idx_stride, stream);
+        else rc = launch_sk_small<64>(r, cb, K, pairs_dev, nb, maxg, eps, iters, idx_out, idx_stride, stream);
+        if (rc) return rc;
+    }
+    // larger problems (a training batch) go through the multi-launch path, one at a time
+    for (int g = 0; g < G; ++g) {
+        const int64_t sz = offs[g + 1] - offs[g];
+        if (sz * K > SKS_MAX) {
+            int rc = sinkhorn_big(r + offs[g] * e, sz, e, cb, K, eps, iters, idx_out + offs[g] * idx_stride, idx_stride, ws, stream);
+            if (rc) return rc;
+        }
+    }
+    return LCREC_OK;
+}
+
+int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, const int64_t *idx, int64_t idx_stride,
+                float *xq, int xq_accumulate, float *r_out, double *sse_out, void *workspace, size_t workspace_bytes,
+                hipStream_t stream)
+{
+    if (!r_in || !cb || !idx) return fail(LCREC_EINVAL, "rq_apply_level: NULL pointer");
+    if (e % 4 || e <= 0 || K < 1 || n < 0) return fail(LCREC_EINVAL, "rq_apply_level: bad shape");
+    if (n == 0) return LCREC_OK;
+    int64_t blocks = (n * (e / 4) + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    double *partial = nullptr;
+    if (sse_out) {
+        if (!workspace || workspace_bytes < 1024 * sizeof(double))
+            return fail(LCREC_EWORKSPACE, "rq_apply_level: workspace %zu B < required %zu B", workspace_bytes, 1024 * sizeof(double));
+        partial = reinterpret_cast<double *>(workspace);
+    }
+    TraceScope trace(K_APPLY_LEVEL, stream);
+    hipLaunchKernelGGL(apply_level_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r_in, n, e, cb, K, idx, idx_stride, xq,
+                       xq_accumulate, r_out, partial);
+    if (sse_out) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, partial, (int)blocks, sse_out);
+    return check_launch("apply_level_kernel");
+}
+
+int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
+               float *sum, hipStream_t stream)
+{
+    if (!idx || !resid || !count || !sum) return fail(LCREC_EINVAL, "code_stats: NULL pointer");
+    if (n < 0 || K < 1) return fail(LCREC_EINVAL, "code_stats: bad shape");
+    TraceScope trace(K_CODE_STATS, stream);
+    if (e == 16) hipLaunchKernelGGL(code_stats_kernel<16>, dim3((K + 15) / 16), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);
+    else if (e == 32) hipLaunchKernelGGL(code_stats_kernel<32>, dim3((K + 7) / 8), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);
+    else if (e == 64) hipLaunchKernelGGL(code_stats_kernel<64>, dim3((K + 3) / 4), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);
+    else return fail(LCREC_EUNSUPPORTED, "code_stats: e_dim=%d (supported: 16, 32, 64)", e);
+    return check_launch("code_stats_kernel");
+}
+
+int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,
+               float decay, float alpha, float keep, float eps, hipStream_t stream)
+{
+    if (!ema_count || !ema_sum || !codebook || !count || !sum) return fail(LCREC_EINVAL, "ema_update: NULL pointer");
+    if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "ema_update: e_dim=%d (supported: 16, 32, 64)", e);
+    const int64_t total = (int64_t)K * e;
+    TraceScope trace(K_EMA_UPDATE, stream);
+    hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ema_count, ema_sum, codebook,
+                       count, sum, K, e, decay, alpha, keep, eps);
+    return check_launch("ema_update_kernel");
+}
+
+}  // namespace lcrec

@@ -76,10 +76,12 @@ def flatten_codebooks(codebooks):
     return flat, ks
 
 
-def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=False):
+def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=False, xq_init=None):
     """ResidualVectorQuantizer.forward values with use_sk=False (rq.py:39-55).
 
-    Returns (idx int64 [n, L], xq [n, e] | None, sse float64 [L] | None, resid [L, n, e] | None)."""
+    xq_init: optional [n, e] tensor that the x_q sum starts from (it is updated in place and returned).
+    Returns (idx int64 [n, L], xq [n, e] | None, sse float64 [L] | None, resid [L+1, n, e] | None);
+    resid[l] is the residual entering level l, resid[L] the residual left after the last level."""
     lib = _lib.load()
     z = _dev(z, "z")
     cb = _dev(codebooks_flat, "codebooks")
@@ -87,15 +89,20 @@ def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=F
     L = len(ks)
     dev = z.device
     idx = torch.empty((n, L), dtype=torch.int64, device=dev)
-    xq = torch.empty((n, e), dtype=torch.float32, device=dev) if want_xq else None
+    if xq_init is not None:
+        xq = _dev(xq_init, "xq_init")
+        if xq.data_ptr() != xq_init.data_ptr() or tuple(xq.shape) != (n, e):
+            raise _lib.LcrecError("xq_init must be a contiguous [n, e] float32 device tensor")
+    else:
+        xq = torch.empty((n, e), dtype=torch.float32, device=dev) if want_xq else None
     sse = torch.zeros(L, dtype=torch.float64, device=dev) if want_sse else None
-    resid = torch.empty((L, n, e), dtype=torch.float32, device=dev) if want_resid else None
+    resid = torch.empty((L + 1, n, e), dtype=torch.float32, device=dev) if want_resid else None
     karr = _ints(ks)
     with torch.cuda.device(dev):
         nbytes = lib.lcrec_rq_assign_workspace(n, e, karr, L)
         ws = _workspace(nbytes, dev)
-        rc = lib.lcrec_rq_assign(_ptr(z), n, e, _ptr(cb), karr, L, _ptr(idx), _ptr(xq), _ptr(sse), _ptr(resid),
-                                 _ptr(ws), ws.numel(), _stream_ptr())
+        rc = lib.lcrec_rq_assign(_ptr(z), n, e, _ptr(cb), karr, L, _ptr(idx), _ptr(xq), int(xq_init is not None),
+                                 _ptr(sse), _ptr(resid), _ptr(ws), ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_rq_assign")
     return idx, xq, sse, resid
 
@@ -139,6 +146,94 @@ def encode_assign(x, weights, biases, codebooks_flat, ks, bn_scales=None, bn_shi
                                      _ptr(latent), _ptr(xq), _ptr(sse), _ptr(ws), ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_encode_assign")
     return idx, latent, xq, sse
+
+
+def _idx_col(idx, n):
+    """(tensor, element stride) for an int64 index column: a [n] vector or a column view of [n, L]."""
+    if not idx.is_cuda or idx.dtype != torch.int64 or idx.dim() != 1 or idx.shape[0] != n:
+        raise _lib.LcrecError("idx must be an int64 device vector of length n (a column view is fine)")
+    return idx, int(idx.stride(0)) if n > 1 else 1
+
+
+def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=None):
+    """use_sk branch of VectorQuantizer.forward (vq.py:76-83): int64 [n] Sinkhorn assignments.
+
+    group_offsets: host sequence of ascending row offsets delimiting independent problems
+    (default: one group = all rows, the training case).  `out` may be a column view of [n, L]."""
+    lib = _lib.load()
+    resid = _dev(resid, "resid")
+    codebook = _dev(codebook, "codebook")
+    n, e = resid.shape
+    K = codebook.shape[0]
+    offs = [0, n] if group_offsets is None else [int(v) for v in group_offsets]
+    G = len(offs) - 1
+    if out is None:
+        out = torch.zeros(n, dtype=torch.int64, device=resid.device)
+    out, stride = _idx_col(out, n)
+    oarr = (ctypes.c_int64 * len(offs))(*offs)
+    with torch.cuda.device(resid.device):
+        nbytes = lib.lcrec_sinkhorn_assign_workspace(n, K, oarr, G)
+        ws = _workspace(nbytes, resid.device)
+        rc = lib.lcrec_sinkhorn_assign(_ptr(resid), n, e, _ptr(codebook), K, oarr, G, float(epsilon), int(iters),
+                                       _ptr(out), stride, _ptr(ws), ws.numel(), _stream_ptr())
+    _lib.check(rc, "lcrec_sinkhorn_assign")
+    return out
+
+
+def rq_apply_level(resid, codebook, idx, xq=None, want_sse=False):
+    """Gather + STE + residual update of one level for given indices (vq.py:87-95, rq.py:47-48).
+
+    xq: None (start a new x_q sum) or the running [n, e] sum, updated in place.
+    Returns (xq, resid_next, sse float64 [1] | None)."""
+    lib = _lib.load()
+    resid = _dev(resid, "resid")
+    codebook = _dev(codebook, "codebook")
+    n, e = resid.shape
+    K = codebook.shape[0]
+    idx, stride = _idx_col(idx, n)
+    accumulate = xq is not None
+    if xq is None:
+        xq = torch.empty((n, e), dtype=torch.float32, device=resid.device)
+    elif not (xq.is_cuda and xq.is_contiguous() and xq.dtype == torch.float32 and tuple(xq.shape) == (n, e)):
+        raise _lib.LcrecError("xq must be a contiguous [n, e] float32 device tensor")
+    nxt = torch.empty_like(resid)
+    sse = torch.zeros(1, dtype=torch.float64, device=resid.device) if want_sse else None
+    with torch.cuda.device(resid.device):
+        ws = _workspace(8192, resid.device)
+        rc = lib.lcrec_rq_apply_level(_ptr(resid), n, e, _ptr(codebook), K, _ptr(idx), stride, _ptr(xq),
+                                      int(accumulate), _ptr(nxt), _ptr(sse), _ptr(ws), ws.numel(), _stream_ptr())
+    _lib.check(rc, "lcrec_rq_apply_level")
+    return xq, nxt, sse
+
+
+def code_stats(idx, resid, K):
+    """count [K] and per-code residual sums [K, e] in item order (index_improve vq.py:151-167)."""
+    lib = _lib.load()
+    resid = _dev(resid, "resid")
+    n, e = resid.shape
+    idx, stride = _idx_col(idx, n)
+    count = torch.empty(K, dtype=torch.float32, device=resid.device)
+    total = torch.empty((K, e), dtype=torch.float32, device=resid.device)
+    with torch.cuda.device(resid.device):
+        rc = lib.lcrec_code_stats(_ptr(idx), stride, _ptr(resid), n, e, K, _ptr(count), _ptr(total), _stream_ptr())
+    _lib.check(rc, "lcrec_code_stats")
+    return count, total
+
+
+def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps):
+    """In-place EMA step of index_improve vq.py:155-184 on three contiguous fp32 device tensors."""
+    lib = _lib.load()
+    for name, t in (("ema_count", ema_count), ("ema_sum", ema_sum), ("codebook", codebook)):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise _lib.LcrecError(f"{name} must be a contiguous float32 device tensor (it is updated in place)")
+    count, total = _dev(count, "count"), _dev(total, "sum")
+    K, e = codebook.shape
+    alpha = 1 - decay                  # the reference's python doubles, rounded to fp32 at the ABI
+    keep = 1 - (1 - decay)
+    with torch.cuda.device(codebook.device):
+        rc = lib.lcrec_ema_update(_ptr(ema_count), _ptr(ema_sum), _ptr(codebook), _ptr(count), _ptr(total), K, e,
+                                  decay, alpha, keep, eps, _stream_ptr())
+    _lib.check(rc, "lcrec_ema_update")
 
 
 def trace_enable(on=True):

@@ -111,7 +111,7 @@ def rq_assign(z, codebooks, want_resid=False):
     idx = np.empty((n, L), dtype=np.int64)
     xq = np.empty((n, e), dtype=np.float32)
     sse = np.zeros(L, dtype=np.float64)
-    resid = np.empty((L, n, e), dtype=np.float32) if want_resid else None
+    resid = np.empty((L + 1, n, e), dtype=np.float32) if want_resid else None
     rc = lib().lcrec_oracle_rq_assign(_p(z), n, e, _p(cb), _p(Ks, _i32p), L, _p(idx, _i64p), _p(xq), _p(sse, _f64p),
                                       _p(resid))
     assert rc == 0, rc
@@ -188,3 +188,17 @@ def ema_update(ema_count, ema_sum, codebook, count, s, decay, eps):
                                        np.float32(decay), alpha, keep, np.float32(eps))
     assert rc == 0, rc
     return ema_count, ema_sum, codebook
+
+
+def distances(z, codebook):
+    """vq.py:71-73 as a [n, K] fp32 matrix in the canonical fma-chain order."""
+    z, cb = _f32(z), _f32(codebook)
+    n, e = z.shape
+    K = cb.shape[0]
+    d = np.empty((n, K), dtype=np.float32)
+    fn = lib().lcrec_oracle_distances
+    fn.restype = ctypes.c_int
+    fn.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, ctypes.c_int, _f32p]
+    rc = fn(_p(z), n, e, _p(cb), K, _p(d))
+    assert rc == 0, rc
+    return d

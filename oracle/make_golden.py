@@ -1,0 +1,358 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by importing and running the real reference in THIS container.
+
+    python oracle/make_golden.py            # needs /root/reference (never present on the GPU box)
+
+The reference ships no tests or golden vectors of its own, so parity is
+pinned by outputs of the reference itself, produced here and committed as small fixtures:
+inputs come from tests/golden_inputs.py (seeded numpy) or are stored next to the outputs.
+
+Every fixture is also replayed through the two oracles at generation time and the outcome is
+recorded in tests/golden/manifest.json:
+  * oracle/torch_ref.py must equal the reference bit for bit (same aten ops, same machine);
+  * oracle/lcrec_oracle.c (canonical fma-chain order) must give the same indices and floats
+    within 1e-5 -- the number of differing rows is recorded, never hidden.
+"""
+import argparse
+import contextlib
+import copy
+import hashlib
+import io
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import golden_inputs as gi  # noqa: E402
+from oracle import cpu_oracle, torch_ref  # noqa: E402
+
+
+def load_reference(subdir):
+    """Import the reference's `models` package (and friends) from index/ or index_improve/."""
+    for name in list(sys.modules):
+        if name == "models" or name.startswith("models.") or name in ("datasets", "trainer", "utils"):
+            del sys.modules[name]
+    path = os.path.join(REF, subdir)
+    sys.path[:] = [p for p in sys.path if not p.startswith(REF)]
+    sys.path.insert(0, path)
+    import models.layers as layers
+    import models.rq as rq
+    import models.rqvae as rqvae
+    import models.vq as vq
+    return dict(layers=layers, rq=rq, rqvae=rqvae, vq=vq, path=path)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    return name
+
+
+# --------------------------------------------------------------------------- F1 / F2
+def ref_rq(ref, z, cbs, beta=0.25):
+    L, e = len(cbs), z.shape[1]
+    m = ref["rq"].ResidualVectorQuantizer([c.shape[0] for c in cbs], e, sk_epsilons=[0.0] * L, beta=beta,
+                                          kmeans_init=False)
+    for l, c in enumerate(cbs):
+        m.vq_layers[l].embedding.weight.data.copy_(t(c))
+    m.eval()
+    with torch.no_grad():
+        xq, loss, idx = m(t(z), use_sk=False)
+    return xq.numpy(), float(loss), idx.numpy()
+
+
+def fixture_rq(ref, manifest):
+    for levels, codes in ((4, 256), (8, 1024)):
+        z, cbs = gi.rq_kat(levels, codes)
+        xq, loss, idx = ref_rq(ref, z, cbs)
+        # torch_ref must be bit-identical
+        xq2, loss2, idx2 = torch_ref.rq(t(z), [t(c) for c in cbs], 0.25, False, [0.0] * levels, 50)
+        assert np.array_equal(xq2.numpy(), xq) and float(loss2) == loss and np.array_equal(idx2.numpy(), idx)
+        o = cpu_oracle.rq_assign(z, cbs)
+        n, e = z.shape
+        oloss = float(np.mean([(1 + 0.25) * s / (n * e) for s in o["sse"]]))
+        name = save(f"f1_rq_{levels}x{codes}.npz", idx=idx.astype(np.int16), xq=xq, rq_loss=np.float32(loss))
+        manifest["fixtures"][name] = {
+            "pins": "rq.py:39-55 / vq.py:63-99 (use_sk=False)", "inputs": f"golden_inputs.rq_kat({levels}, {codes})",
+            "c_oracle_idx_mismatch_rows": int((o["idx"] != idx).any(1).sum()),
+            "c_oracle_xq_max_abs_err": float(np.abs(o["xq"] - xq).max()),
+            "c_oracle_loss_rel_err": abs(oloss - loss) / abs(loss), "torch_ref_bit_identical": True}
+
+    z, cb = gi.tie_case()
+    _, _, idx = ref_rq(ref, z, [cb, cb])
+    o = cpu_oracle.rq_assign(z, [cb, cb])
+    name = save("f2_ties.npz", idx=idx.astype(np.int16))
+    manifest["fixtures"][name] = {
+        "pins": "vq.py:75 argmin first-index tie-break on exactly representable distances",
+        "inputs": "golden_inputs.tie_case()", "c_oracle_idx_mismatch_rows": int((o["idx"] != idx).any(1).sum())}
+    assert manifest["fixtures"][name]["c_oracle_idx_mismatch_rows"] == 0
+
+
+# --------------------------------------------------------------------------- F3
+def fixture_sinkhorn(ref, manifest):
+    vqm = ref["vq"].VectorQuantizer(256, 32, sk_epsilon=0.003, sk_iters=50)
+    for B in (8, 2048):
+        z, cb = gi.sinkhorn_case(B)
+        vqm.embedding.weight.data.copy_(t(cb))
+        vqm.eval()
+        with torch.no_grad():
+            _, _, idx = vqm(t(z), use_sk=True)
+            d = torch_ref.distances(t(z), t(cb))
+            Q = ref["layers"].sinkhorn_algorithm(vqm.center_distance_for_constraint(d).double(), 0.003, 50)
+        Q2 = torch_ref.sinkhorn(torch_ref.centre_distances(d).double(), 0.003, 50)
+        assert torch.equal(Q, Q2) and torch.equal(torch.argmax(Q, -1), idx)
+        top2 = torch.topk(Q, 2, dim=-1).values
+        name = save(f"f3_sinkhorn_{B}.npz", idx=idx.numpy().astype(np.int16), row_sum=Q.sum(1).numpy(),
+                    col_sum=Q.sum(0).numpy(), qmax=top2[:, 0].numpy(),
+                    margin=((top2[:, 0] - top2[:, 1]) / top2[:, 0]).numpy())
+        manifest["fixtures"][name] = {
+            "pins": "vq.py:51-61,76-83 + layers.py:85-108 (eps 0.003, 50 iterations, fp64)",
+            "inputs": f"golden_inputs.sinkhorn_case({B})", "torch_ref_bit_identical": True,
+            "argmin_vs_sinkhorn_differ_rows": int((torch.argmin(d, -1) != idx).sum())}
+
+
+# --------------------------------------------------------------------------- F4
+def fixture_train_step(ref, manifest):
+    from transformers import get_linear_schedule_with_warmup
+    for bn in (False, True):
+        torch.manual_seed(2024)
+        spec_kw = dict(in_dim=128, num_emb_list=[256] * 4, e_dim=16, layers=[64, 32], dropout_prob=0.0, bn=bn,
+                       loss_type="mse", quant_loss_weight=1.0, beta=0.25, kmeans_init=False, kmeans_iters=100,
+                       sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+        model = ref["rqvae"].RQVAE(**spec_kw)
+        x = t(gi.f32(gi.rs(400 + int(bn)).standard_normal((256, 128))))
+        # data-scale codebooks: rows of the level's residual (stand-in for k-means, which is sklearn and unpinned)
+        model.train()
+        with torch.no_grad():
+            resid = model.encoder(x)
+            g = torch.Generator().manual_seed(7)
+            for l in range(4):
+                pick = torch.randperm(256, generator=g)
+                cb = resid[pick] + 0.01 * torch.randn(256, 16, generator=g)
+                model.rq.vq_layers[l].embedding.weight.data.copy_(cb)
+                d = torch_ref.distances(resid, cb)
+                resid = resid - cb[torch.argmin(d, -1)]
+        if bn:   # undo the running-stat updates of the probe pass
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        arrays = {"sd__" + k: v.numpy() for k, v in sd0.items()}
+
+        spec = torch_ref.Spec(128, [256] * 4, 16, [64, 32], bn=bn, sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+        # ---- eval-mode values from the initial state
+        model.eval()
+        with torch.no_grad():
+            out_e, rql_e, idx_e = model(x, use_sk=False)
+            idx_g = model.get_indices(x)
+            lt_e, lr_e = model.compute_loss(out_e, rql_e, xs=x)
+            latent_e = model.encoder(x)
+            sde = {k: v.clone() for k, v in sd0.items()}
+            o2, r2, i2 = torch_ref.forward(spec, sde, x, use_sk=False, training=False)
+            assert torch.equal(o2, out_e) and torch.equal(r2, rql_e) and torch.equal(i2, idx_e)
+            assert torch.equal(torch_ref.get_indices(spec, sde, x), idx_g)
+        arrays.update(eval_out=out_e.numpy(), eval_rq_loss=rql_e.numpy(), eval_idx=idx_e.numpy().astype(np.int16),
+                      eval_loss_total=lt_e.numpy(), eval_loss_recon=lr_e.numpy(), eval_latent=latent_e.numpy())
+        # C oracle on the eval path
+        nl = 3
+        names = gi.state_dict_names(nl, bn, 4)
+        Ws = [sd0[n + ".weight"].numpy() for n in names["encoder"]]
+        bs = [sd0[n + ".bias"].numpy() for n in names["encoder"]]
+        scs, shs = [], []
+        for l in range(nl):
+            if bn and l < nl - 1:
+                b = names["bn"]["encoder"][l]
+                sc, sh = gi.fold_bn({k: sd0[f"{b}.{k}"].numpy() for k in ("weight", "bias", "running_mean", "running_var")})
+            else:
+                sc, sh = None, None
+            scs.append(sc)
+            shs.append(sh)
+        o = cpu_oracle.encode_assign(x.numpy(), Ws, bs, [sd0[n].numpy() for n in names["codebooks"]], scs, shs)
+        c_mis = int((o["idx"] != idx_g.numpy()).any(1).sum())
+        c_lat = float(np.abs(o["latent"] - latent_e.numpy()).max())
+
+        # ---- three optimisation steps exactly as trainer.py:111-120 (use_sk=True, AdamW, linear warm-up)
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        sched = get_linear_schedule_with_warmup(optimizer=opt, num_warmup_steps=2, num_training_steps=10)
+        traj = []
+        sd_t = {k: v.clone() for k, v in sd0.items()}
+        for step in range(3):
+            opt.zero_grad()
+            out, rq_loss, idx = model(x)
+            loss, recon = model.compute_loss(out, rq_loss, xs=x)
+            if step == 0:
+                # torch_ref forward in training mode must match bit for bit
+                leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k
+                            else v.clone()) for k, v in sd_t.items()}
+                o2, r2, i2 = torch_ref.forward(spec, leaf, x, use_sk=True, training=True)
+                l2, rc2 = torch_ref.compute_loss(spec, o2, r2, x)
+                assert torch.equal(o2, out) and torch.equal(r2, rq_loss) and torch.equal(i2, idx) and torch.equal(l2, loss)
+                l2.backward()
+            loss.backward()
+            if step == 0:
+                for k, p in model.named_parameters():
+                    assert torch.equal(leaf[k].grad, p.grad), k
+                arrays.update(train_out=out.detach().numpy(), train_idx=idx.numpy().astype(np.int16),
+                              train_rq_loss=rq_loss.detach().numpy(), train_loss=loss.detach().numpy(),
+                              train_recon=recon.detach().numpy())
+                for k, p in model.named_parameters():
+                    arrays["grad__" + k] = p.grad.numpy().copy()
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            sched.step()
+            traj.append([float(loss), float(recon), float(rq_loss), float(gn), float(sched.get_last_lr()[0])])
+            if step == 0:
+                for k, v in model.state_dict().items():
+                    arrays["step1__" + k] = v.numpy().copy()
+        arrays["trajectory"] = np.asarray(traj, dtype=np.float64)   # loss, recon, rq_loss, grad_norm, lr-after-step
+        name = save(f"f4_step_bn{int(bn)}.npz", **arrays)
+        manifest["fixtures"][name] = {
+            "pins": "rqvae.py:61-85 forward/compute_loss; trainer.py:111-120 one step (clip 1.0, AdamW lr 1e-3 wd 1e-4, "
+                    "linear warm-up 2/10); autograd through STE",
+            "inputs": f"x = golden_inputs.rs({400 + int(bn)}).standard_normal((256,128)); state dict stored (sd__*)",
+            "model": {k: v for k, v in spec_kw.items()}, "torch_ref_bit_identical": True,
+            "c_oracle_idx_mismatch_rows": c_mis, "c_oracle_latent_max_abs_err": c_lat}
+
+
+# --------------------------------------------------------------------------- F5
+def fixture_ema(manifest):
+    ref = load_reference("index_improve")
+    r = gi.rs(500)
+    z = gi.f32(r.standard_normal((512, 32)))
+    cb = gi.f32(r.standard_normal((256, 32)) * 0.9)
+    cb[200:] *= 40.0      # far-away codes nobody selects: exercises the "used" mask
+    m = ref["vq"].VectorQuantizer(256, 32, beta=0.25, kmeans_init=False, sk_epsilon=0.0, sk_iters=50, ema_decay=0.99,
+                                  epsilon=1e-5, reset_threshold=1e-5, reset_interval=1000)
+    m.embedding.weight.data.copy_(t(cb))
+    m._ema_cluster_size.copy_(t(gi.f32(r.uniform(0, 3, size=256))))
+    m._ema_cluster_size[200:] = 0
+    m._ema_w.copy_(t(gi.f32(r.standard_normal((256, 32)))))
+    ema_n0, ema_w0 = m._ema_cluster_size.clone(), m._ema_w.clone()
+    m.train()
+    xq, loss, idx = m(t(z), use_sk=False, use_ema=True)
+    usage = m.get_codebook_usage()
+    # torch_ref replay
+    cb2, n2, w2 = t(cb).clone(), ema_n0.clone(), ema_w0.clone()
+    count, dw = torch_ref.ema_step(cb2, n2, w2, t(z), idx, 0.99, 1e-5)
+    assert torch.equal(cb2, m.embedding.weight.data) and torch.equal(n2, m._ema_cluster_size) and torch.equal(w2, m._ema_w)
+    assert torch_ref.utilisation(n2, 1e-5, 1e-5) == usage
+    # C oracle replay
+    c_cnt, c_sum = cpu_oracle.code_stats(idx.numpy(), z, 256)
+    assert np.array_equal(c_cnt, count.numpy()) and np.array_equal(c_sum, dw.numpy())
+    en, ew, ecb = cpu_oracle.ema_update(ema_n0.numpy(), ema_w0.numpy(), cb, c_cnt, c_sum, 0.99, 1e-5)
+    name = save("f5_ema.npz", ema_count0=ema_n0.numpy(), ema_sum0=ema_w0.numpy(), idx=idx.numpy().astype(np.int16),
+                count=count.numpy(), sum=dw.numpy(), ema_count1=m._ema_cluster_size.numpy(), ema_sum1=m._ema_w.numpy(),
+                codebook1=m.embedding.weight.data.numpy(), used_codes=np.int64(usage["used_codes"]))
+    manifest["fixtures"][name] = {
+        "pins": "index_improve/models/vq.py:147-184 (EMA step), :205-217 (utilisation)",
+        "inputs": "rs(500): z [512,32], codebook [256,32] (rows 200+ scaled x40), EMA buffers stored",
+        "torch_ref_bit_identical": True, "c_oracle_count_sum_bit_identical": True,
+        "c_oracle_ema_count_max_abs_err": float(np.abs(en - m._ema_cluster_size.numpy()).max()),
+        "c_oracle_ema_sum_max_abs_err": float(np.abs(ew - m._ema_w.numpy()).max()),
+        "c_oracle_codebook_max_abs_err": float(np.abs(ecb - m.embedding.weight.data.numpy()).max())}
+    return ref
+
+
+# --------------------------------------------------------------------------- F8
+def fixture_encoder(ref, manifest):
+    for in_dim, n, bn in ((768, 2048, False), (768, 1024, True), (4096, 512, False)):
+        dims, Ws, bs, bns, x = gi.encoder_case(in_dim, n, bn=bn)
+        model = ref["rqvae"].RQVAE(in_dim=in_dim, num_emb_list=[256] * 4, e_dim=32, layers=gi.RUN_SH_LAYERS, bn=bn,
+                                   kmeans_init=False, sk_epsilons=[0.0] * 4, sk_iters=50)
+        names = gi.state_dict_names(len(Ws), bn, 4)
+        sd = model.state_dict()
+        for l, nme in enumerate(names["encoder"]):
+            sd[nme + ".weight"] = t(Ws[l])
+            sd[nme + ".bias"] = t(bs[l])
+        if bn:
+            for l, nme in enumerate(names["bn"]["encoder"]):
+                for k, v in bns[l].items():
+                    sd[f"{nme}.{k}"] = t(v)
+        model.load_state_dict(sd)
+        model.eval()
+        with torch.no_grad():
+            lat = model.encoder(t(x))
+        # data-scale codebooks from the first 256-row block of reference latents (stored: they depend on MKL)
+        r = gi.rs(900 + in_dim + n)
+        cbs, resid = [], lat.numpy().copy()
+        for l in range(4):
+            cb = gi.f32(resid[r.permutation(n)[:256]] + 0.003 * r.standard_normal((256, 32)))
+            cbs.append(cb)
+            d = torch_ref.distances(t(resid), t(cb))
+            resid = resid - cb[torch.argmin(d, -1).numpy()]
+        for l in range(4):
+            model.rq.vq_layers[l].embedding.weight.data.copy_(t(cbs[l]))
+        with torch.no_grad():
+            idx = model.get_indices(t(x))
+            idx64 = torch.cat([model.get_indices(t(x[i:i + 64])) for i in range(0, n, 64)])
+        scs, shs = zip(*[gi.fold_bn(b) for b in bns])
+        o = cpu_oracle.encode_assign(x, Ws, bs, cbs, list(scs), list(shs), threads=8)
+        name = save(f"f8_encode_{in_dim}_bn{int(bn)}.npz", idx=idx.numpy().astype(np.int16), latent=lat.numpy(),
+                    codebooks=np.stack(cbs), idx_batch64=idx64.numpy().astype(np.int16))
+        manifest["fixtures"][name] = {
+            "pins": "rqvae.py:68-72 get_indices at the run.sh architecture (4x256, e 32, MLP 2048-...-64)",
+            "inputs": f"golden_inputs.encoder_case({in_dim}, {n}, bn={bn}); codebooks stored",
+            "reference_self_mismatch_rows_batch_n_vs_64": int((idx64 != idx).any(1).sum()),
+            "c_oracle_idx_mismatch_rows": int((o["idx"] != idx.numpy()).any(1).sum()),
+            "c_oracle_latent_max_abs_err": float(np.abs(o["latent"] - lat.numpy()).max()),
+            "latent_abs_max": float(np.abs(lat.numpy()).max())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    mpath = os.path.join(OUT, "manifest.json")
+    manifest = {"fixtures": {}}
+    if args.only and os.path.exists(mpath):
+        manifest = json.load(open(mpath))
+    manifest["generated_with"] = {
+        "torch": torch.__version__, "numpy": np.__version__, "reference": "jiaozihao18/LC-Rec @ /root/reference",
+        "cpu_threads": torch.get_num_threads(), "c_oracle_simd": int(cpu_oracle.lib().lcrec_oracle_simd())}
+    want = set(args.only.split(",")) if args.only else None
+    ref = load_reference("index")
+    steps = [("rq", lambda: fixture_rq(ref, manifest)), ("sinkhorn", lambda: fixture_sinkhorn(ref, manifest)),
+             ("step", lambda: fixture_train_step(ref, manifest)), ("encoder", lambda: fixture_encoder(ref, manifest))]
+    for name, fn in steps:
+        if want is None or name in want:
+            print("generating", name, flush=True)
+            fn()
+    if want is None or "ema" in want:
+        print("generating ema", flush=True)
+        fixture_ema(manifest)
+    for name in list(manifest["fixtures"]):
+        p = os.path.join(OUT, name)
+        if os.path.exists(p):
+            manifest["fixtures"][name]["sha256"] = sha(p)
+            manifest["fixtures"][name]["bytes"] = os.path.getsize(p)
+    with open(mpath, "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk.startswith(("c_oracle", "reference_self", "bytes"))}
+                      for k, v in manifest["fixtures"].items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
