@@ -153,6 +153,23 @@ int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook, const fl
                      const float *sum, int K, int e, float decay, float alpha, float keep, float eps,
                      void *stream);
 
+/* Which items share an identical index tuple.  Replaces the Python string-set / dict passes of
+ * index/trainer.py:139-150 (collision rate) and index/generate_indices.py:18-42
+ * (check_collision, get_indices_count, get_collision_item), keeping get_collision_item's order:
+ * groups (tuples held by >= 2 items) by first occurrence of the tuple in item order, item ids
+ * ascending inside a group.
+ *   idx               device [n][L] int64, K host [L] (codes per level; sum of ceil(log2 K) <= 128)
+ *   members_out       device [n] int64 or NULL: ids of the items of all groups, group after group
+ *   group_offsets_out device [n/2+2] int64 or NULL (given together with members_out):
+ *                     group g = members_out[off[g] .. off[g+1])
+ *   counters_out      device int64[4]: {distinct tuples, groups, items in groups, largest tuple count}
+ *                     (entries 1 and 2 only when members_out is given);
+ *                     collision_rate = (n - counters[0]) / n */
+size_t lcrec_collision_groups_workspace(int64_t n, int L);
+int lcrec_collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t *members_out,
+                           int64_t *group_offsets_out, int64_t *counters_out, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* Kernel tracing (diagnostic; the reference has no tracing on this path -- its only
  * timing is wall-clock per epoch, index/trainer.py:193-195).  While enabled, every
  * kernel this library launches is bracketed by a pair of hipEvents recorded on the

@@ -46,6 +46,9 @@ _SIGNATURES = {
                                         _vp, _vp, _vp]),
     "lcrec_ema_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+    "lcrec_collision_groups_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
+    "lcrec_collision_groups": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _vp,
+                                              _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_trace_enable": (ctypes.c_int, [ctypes.c_int]),
     "lcrec_trace_collect": (ctypes.c_int, [_vp, ctypes.c_int]),
 }

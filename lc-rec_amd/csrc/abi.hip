@@ -23,7 +23,8 @@ int fail(int code, const char *fmt, ...)
 
 const char *const kKernelNames[K_COUNT] = {"linear_fwd_128x128", "linear_fwd_128x64", "linear_fwd_128x32",
                                            "rq_assign", "rq_sse_finalize", "vq_distance", "sinkhorn",
-                                           "sinkhorn_small", "rq_apply_level", "code_stats", "ema_update"};
+                                           "sinkhorn_small", "rq_apply_level", "code_stats", "ema_update",
+                                           "collision_groups"};
 
 struct TraceRec { int kernel; hipEvent_t start, stop; };
 static std::mutex g_trace_mu;
@@ -212,4 +213,14 @@ LCREC_API int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook
                                void *stream)
 {
     return ema_update(ema_count, ema_sum, codebook, count, sum, K, e, decay, alpha, keep, eps, (hipStream_t)stream);
+}
+
+LCREC_API size_t lcrec_collision_groups_workspace(int64_t n, int L) { return collision_workspace(n, L); }
+
+LCREC_API int lcrec_collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t *members_out,
+                                     int64_t *group_offsets_out, int64_t *counters_out, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    return collision_groups(idx, n, L, K, members_out, group_offsets_out, counters_out, workspace, workspace_bytes,
+                            (hipStream_t)stream);
 }

@@ -28,7 +28,7 @@ inline int check_launch(const char *what)
 
 // Kernel ids for lcrec_trace_*.
 enum KernelId { K_LINEAR_128x128 = 0, K_LINEAR_128x64, K_LINEAR_128x32, K_RQ_ASSIGN, K_RQ_SSE_FINALIZE,
-                K_VQ_DISTANCE, K_SINKHORN, K_SINKHORN_SMALL, K_APPLY_LEVEL, K_CODE_STATS, K_EMA_UPDATE, K_COUNT };
+                K_VQ_DISTANCE, K_SINKHORN, K_SINKHORN_SMALL, K_APPLY_LEVEL, K_CODE_STATS, K_EMA_UPDATE, K_COLLISION, K_COUNT };
 extern const char *const kKernelNames[K_COUNT];
 bool trace_on();
 void trace_begin(int kernel, hipStream_t stream);
@@ -63,6 +63,9 @@ int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, con
                 hipStream_t stream);
 int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
                float *sum, hipStream_t stream);
+size_t collision_workspace(int64_t n, int L);
+int collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t *members_out, int64_t *offsets_out,
+                     int64_t *counters_out, void *workspace, size_t workspace_bytes, hipStream_t stream);
 int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,
                float decay, float alpha, float keep, float eps, hipStream_t stream);
 

@@ -1,0 +1,88 @@
+"""Item-embedding input -- mirror of the reference's index/datasets.py (EmbDataset :6-21) plus the
+device-resident loader the MI355X trainer iterates instead of a worker-process DataLoader.
+
+Contract kept from the reference: `np.load` of an [N, d] float array (the `.emb-*-td.npy` written
+by data_process/amazon_text_emb.py:101-105), `.dim`, `len()`, and `__getitem__` returning a
+float32 tensor -- also for a LIST of indices (generate_indices.py:117 fancy-indexes collision
+groups).
+"""
+import numpy as np
+import torch
+import torch.utils.data as data
+
+
+class EmbDataset(data.Dataset):
+
+    def __init__(self, data_path, mmap=False):
+        self.data_path = data_path
+        self.embeddings = np.load(data_path, mmap_mode="r" if mmap else None)
+        self.dim = self.embeddings.shape[-1]
+        self._device_copy = None
+
+    def __getitem__(self, index):
+        return torch.FloatTensor(np.asarray(self.embeddings[index]))
+
+    def __len__(self):
+        return len(self.embeddings)
+
+    def to_device(self, device, chunk_rows=1 << 18):
+        """The whole matrix as one fp32 tensor in HBM (Games: 16 859 x 4096 = 276 MB; a 288 GB
+        MI355X holds 17 M such rows).  Cast and copied in row chunks so a large or memory-mapped
+        file never needs a second full host copy."""
+        device = torch.device(device)
+        if self._device_copy is not None and self._device_copy.device == device:
+            return self._device_copy
+        n = len(self)
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=device)
+        for lo in range(0, n, chunk_rows):
+            hi = min(n, lo + chunk_rows)
+            block = torch.from_numpy(np.ascontiguousarray(self.embeddings[lo:hi], dtype=np.float32))
+            out[lo:hi].copy_(block, non_blocking=False)
+        self._device_copy = out
+        return out
+
+
+class DeviceLoader:
+    """Batches of a device-resident embedding matrix, with the reference DataLoader's semantics
+    (index/main.py:86: shuffle=True, drop_last=False; generate_indices.py:77: shuffle=False).
+
+    Shuffling reproduces torch's RandomSampler draw sequence from the global CPU generator -- one
+    int64 for the loader iterator's base seed, one for the sampler seed, then
+    torch.randperm(n, generator=Generator().manual_seed(seed)) -- so under `torch.manual_seed(s)`
+    the batch composition is the one the reference's DataLoader yields.  No worker processes, no
+    per-item Python: a batch is one index_select on the GPU.
+    """
+
+    def __init__(self, dataset, batch_size, shuffle, device, rank=0, world_size=1):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.device = torch.device(device)
+        self.rank, self.world_size = rank, world_size
+        self.data = dataset.to_device(self.device) if isinstance(dataset, EmbDataset) else dataset.to(self.device)
+
+    def __len__(self):
+        return (self.data.shape[0] + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = self.data.shape[0]
+        if self.shuffle:
+            torch.empty((), dtype=torch.int64).random_()                       # _BaseDataLoaderIter base seed
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())    # RandomSampler.__iter__
+            g = torch.Generator()
+            g.manual_seed(seed)
+            order = torch.randperm(n, generator=g).to(self.device)
+        else:
+            order = None
+        for lo in range(0, n, self.batch_size):
+            hi = min(n, lo + self.batch_size)
+            if order is None:
+                batch = self.data[lo:hi]
+            else:
+                batch = self.data.index_select(0, order[lo:hi])
+            if self.world_size > 1:
+                # item-sharded data parallel: every rank walks the same global batch and keeps its slice
+                m = batch.shape[0]
+                per = (m + self.world_size - 1) // self.world_size
+                batch = batch[self.rank * per:min(m, (self.rank + 1) * per)]
+            yield batch

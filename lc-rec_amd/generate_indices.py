@@ -1,0 +1,223 @@
+"""Index emission + conflict resolution -- the flow of the reference's index/generate_indices.py
+(:51-145), as functions and a small CLI instead of a script with hard-coded paths (:44-49).
+
+    python -m lcrec_amd.generate_indices --ckpt_path CKPT.pth --output_dir DIR [--dataset Games]
+
+Same observable behaviour: pass 1 = get_indices(use_sk=False) over all items (:77-95); levels
+0..L-2 forced to hard assignment and the last level's sk_epsilon set to 0.003 if it was 0 (:101-105);
+up to 20 rounds in which every group of items sharing a tuple is re-assigned with Sinkhorn on the
+last level (:107-128); statistics (:131-136); `{item: ["<a_i>", "<b_j>", ...]}` written with
+json.dump's default separators (:138-145) so data.py:38-89 reads it unchanged.
+
+What runs where: pass 1 is one lcrec_encode_assign call; the residual entering the last level is
+kept in HBM, so a round is {lcrec_collision_groups -> gather -> ONE batched lcrec_sinkhorn_assign
+over all groups -> scatter}: no re-encoding, no per-group forward, no Python string keys.
+Groups within a round are independent in the reference too (they are listed before any is
+re-assigned), so batching them does not change the result.
+
+Documented divergences from the reference script:
+  * its 5-entry prefix list (:83) raises IndexError for L > 5; here prefixes continue <f_..>, <g_..>;
+  * it stores tokens in fixed-width numpy unicode arrays (:98-99) which silently truncate a
+    replacement longer than anything seen in pass 1; integer tuples are kept here, and a warning is
+    logged if a run ever hits that case (the reference's output would be corrupt there).
+"""
+import argparse
+import collections
+import json
+import logging
+import os
+
+import torch
+
+from . import ops
+from .datasets import EmbDataset
+from .rqvae import RQVAE
+
+PREFIX = ["<{}_{{}}>".format(chr(ord("a") + i)) for i in range(26)]   # "<a_{}>", "<b_{}>", ... (:83 has a..e)
+MAX_ROUNDS = 20                                                        # :110
+log = logging.getLogger(__name__)
+
+
+# ---- the reference's helper API (:18-42), on any sequence of hashable index keys
+def check_collision(all_indices_str):
+    keys = all_indices_str.tolist() if hasattr(all_indices_str, "tolist") else list(all_indices_str)
+    keys = [tuple(k) if isinstance(k, list) else k for k in keys]
+    return len(keys) == len(set(keys))
+
+
+def get_indices_count(all_indices_str):
+    counts = collections.defaultdict(int)
+    for key in all_indices_str:
+        counts[tuple(key) if isinstance(key, list) else key] += 1
+    return counts
+
+
+def get_collision_item(all_indices_str):
+    """Groups of item ids sharing a key: first-occurrence order, ids ascending (:29-42)."""
+    seen = {}
+    for i, key in enumerate(all_indices_str):
+        seen.setdefault(tuple(key) if isinstance(key, list) else key, []).append(i)
+    return [ids for ids in seen.values() if len(ids) > 1]
+
+
+def load_checkpoint(ckpt_path):
+    """torch.load of a trainer checkpoint ({args, epoch, best_*, state_dict, optimizer},
+    trainer.py:158-166) allowing only argparse.Namespace beyond plain tensors."""
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=True)
+    except pickle.UnpicklingError:
+        # trainer.py:167 writes pickle protocol 4, whose FRAME opcode torch's restricted unpickler does
+        # not implement; a trainer checkpoint is the user's own file, so load it the way the reference
+        # does (generate_indices.py:51 predates the weights_only default).
+        log.info("restricted unpickler cannot read %s (protocol 4); loading with weights_only=False", ckpt_path)
+        return torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=False)
+
+
+def build_model_from_args(args, in_dim):
+    """:58-70 -- note beta is NOT forwarded (RQVAE's default 0.25 applies; irrelevant in eval)."""
+    return RQVAE(in_dim=in_dim, num_emb_list=args.num_emb_list, e_dim=args.e_dim, layers=args.layers,
+                 dropout_prob=args.dropout_prob, bn=args.bn, loss_type=args.loss_type,
+                 quant_loss_weight=args.quant_loss_weight, kmeans_init=args.kmeans_init,
+                 kmeans_iters=args.kmeans_iters, sk_epsilons=args.sk_epsilons, sk_iters=args.sk_iters,
+                 ema_decay=getattr(args, "ema_decay", None), epsilon=getattr(args, "epsilon", 1e-5),
+                 reset_threshold=getattr(args, "reset_threshold", 1e-5),
+                 reset_interval=getattr(args, "reset_interval", 1000))
+
+
+@torch.no_grad()
+def assign_all(model, data, chunk_rows=1 << 20):
+    """Pass 1 (:77-95): int64 [N, L] hard indices plus the residual entering the last level."""
+    levels = list(model.rq.vq_layers)
+    Ws, bs, scs, shs = model.encoder.folded()
+    cbs = [q.embedding.weight.detach() for q in levels]
+    flat, ks = ops.flatten_codebooks(cbs)
+    idx_parts, last_parts = [], []
+    for lo in range(0, data.shape[0], chunk_rows):
+        x = data[lo:lo + chunk_rows]
+        idx, latent, _, _ = ops.encode_assign(x, Ws, bs, flat, ks, scs, shs, want_latent=True)
+        idx_parts.append(idx)
+        if len(levels) > 1:
+            pflat, pks = ops.flatten_codebooks(cbs[:-1])
+            _, _, _, resid = ops.rq_assign(latent, pflat, pks, want_resid=True)
+            last_parts.append(resid[len(levels) - 1].clone())
+        else:
+            last_parts.append(latent)
+    return torch.cat(idx_parts), torch.cat(last_parts), ks
+
+
+@torch.no_grad()
+def resolve_collisions(model, idx, resid_last, ks, max_rounds=MAX_ROUNDS, on_round=None):
+    """:101-128.  Mutates and returns idx; also returns the number of groups seen in each round."""
+    levels = list(model.rq.vq_layers)
+    for q in levels[:-1]:
+        q.sk_epsilon = 0.0
+    if levels[-1].sk_epsilon == 0.0:
+        levels[-1].sk_epsilon = 0.003
+    last = levels[-1]
+    cb_last = last.embedding.weight.detach().contiguous()
+    L = len(levels)
+    history = []
+    for _ in range(max_rounds):
+        found = ops.collision_groups(idx, ks, want_groups=True)
+        groups = found["groups"]
+        if not groups:
+            break
+        history.append(len(groups))
+        if on_round is not None:
+            on_round(len(history) - 1, groups)
+        members = torch.tensor([i for g in groups for i in g], dtype=torch.int64, device=idx.device)
+        offsets = [0]
+        for g in groups:
+            offsets.append(offsets[-1] + len(g))
+        rows = resid_last.index_select(0, members)
+        new_last = ops.sinkhorn_assign(rows, cb_last, last.sk_epsilon, last.sk_iters, group_offsets=offsets)
+        idx[members, L - 1] = new_last
+    return idx, history
+
+
+def tokens_for(idx_rows):
+    """[[i, j, ...], ...] -> [["<a_i>", "<b_j>", ...], ...] (:83-92)."""
+    L = len(idx_rows[0]) if idx_rows else 0
+    if L > len(PREFIX):
+        raise ValueError(f"{L} levels: no token prefix beyond <z_..>")
+    return [[PREFIX[l].format(int(v)) for l, v in enumerate(row)] for row in idx_rows]
+
+
+def dump_index_json(idx_rows, path):
+    """Exactly the bytes of `json.dump({item: tokens}, fp)` (:138-145) without building the dict of
+    N Python lists first: keys are item ids in order, separators are json's defaults."""
+    L = len(idx_rows[0]) if idx_rows else 0
+    fmt = '"{0}": [' + ", ".join('"' + PREFIX[l].replace("{}", "{%d}" % (l + 1)) + '"' for l in range(L)) + "]"
+    with open(path, "w") as fp:
+        fp.write("{")
+        step = 1 << 16
+        for lo in range(0, len(idx_rows), step):
+            chunk = idx_rows[lo:lo + step]
+            text = ", ".join(fmt.format(lo + i, *row) for i, row in enumerate(chunk))
+            if lo:
+                fp.write(", ")
+            fp.write(text)
+        fp.write("}")
+
+
+def _warn_if_reference_would_truncate(first_pass_rows, final_rows):
+    def digits(rows):
+        return max((len(str(int(v))) for row in rows for v in row), default=0), \
+            max((sum(len(str(int(v))) for v in row) for row in rows), default=0)
+    tok0, sum0 = digits(first_pass_rows)
+    tok1, sum1 = digits(final_rows)
+    if tok1 > tok0 or sum1 > sum0:
+        log.warning("a re-assigned index is wider than anything in pass 1: the reference's fixed-width numpy "
+                    "string arrays (generate_indices.py:98-99) would truncate it; this output keeps it intact")
+
+
+def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True):
+    """Whole flow of generate_indices.py:51-145.  Returns a dict of the statistics it prints."""
+    ckpt = load_checkpoint(ckpt_path)
+    args = ckpt["args"]
+    data = EmbDataset(data_path or args.data_path)
+    model = build_model_from_args(args, data.dim)
+    model.load_state_dict(ckpt["state_dict"])
+    model = model.to(torch.device(device)).eval()
+    if verbose:
+        print(model)
+    x = data.to_device(device)
+    idx, resid_last, ks = assign_all(model, x)
+    first_pass = idx.tolist()
+
+    def show(round_no, groups):
+        if verbose:
+            print(len(groups))
+
+    idx, history = resolve_collisions(model, idx, resid_last, ks, on_round=show)
+    rows = idx.tolist()
+    _warn_if_reference_would_truncate(first_pass, rows)
+    final = ops.collision_groups(idx, ks, want_groups=False)
+    n = len(rows)
+    stats = {"items": n, "max_conflicts": final["max_count"], "collision_rate": (n - final["unique"]) / n if n else 0.0,
+             "rounds": len(history), "groups_per_round": history}
+    if verbose:
+        print("All indices number: ", n)
+        print("Max number of conflicts: ", stats["max_conflicts"])
+        print("Collision Rate", stats["collision_rate"])
+    os.makedirs(os.path.dirname(os.path.abspath(output_file)), exist_ok=True)
+    dump_index_json(rows, output_file)
+    return stats
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Generate <dataset>.index.json from an RQ-VAE checkpoint")
+    ap.add_argument("--dataset", type=str, default="Games")
+    ap.add_argument("--ckpt_path", type=str, required=True)
+    ap.add_argument("--output_dir", type=str, required=True)
+    ap.add_argument("--data_path", type=str, default=None, help="override the data path stored in the checkpoint")
+    ap.add_argument("--device", type=str, default="cuda:0")
+    a = ap.parse_args(argv)
+    out = os.path.join(a.output_dir, f"{a.dataset}.index.json")
+    return generate(a.ckpt_path, out, device=a.device, data_path=a.data_path)
+
+
+if __name__ == "__main__":
+    main()

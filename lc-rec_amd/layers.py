@@ -1,0 +1,186 @@
+"""MLP stack, k-means seeding and the Sinkhorn entry point -- host-side mirror of the reference's
+index/models/layers.py (MLPLayers :7-43, activation_layer :45-67, kmeans :69-82,
+sinkhorn_algorithm :85-108) with the arithmetic on the MI355X.
+
+The module tree (nn.Sequential of Dropout / Linear / BatchNorm1d / ReLU at the reference's
+indices) is kept because checkpoints are keyed by it (`encoder.mlp_layers.1.weight`, ...); what
+runs is different:
+  * eval / no-grad : one fused fp32-MFMA kernel per layer (bias + folded BatchNorm + ReLU in the
+    GEMM epilogue), see csrc/gemm_f32.hip;
+  * training       : the same kernel for the forward GEMM and for both backward GEMMs
+    (dX = dY W, dW = dY^T X), batch-statistics BatchNorm through torch for now.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.init import xavier_normal_
+
+from . import ops
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = [relu](x W^T + b) with the HIP GEMM in all three products."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = ops.linear_forward(x, weight, bias, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.relu:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear_forward(gy, weight.t().contiguous())          # [n,out] x [out,in]
+        if ctx.needs_input_grad[1]:
+            gw = ops.linear_forward(gy.t().contiguous(), x.t().contiguous())  # [out,n] x [n,in]
+        if ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb, None
+
+
+def fold_batchnorm(bn):
+    """Eval-mode BatchNorm1d as an affine y = t*scale + shift (fp32, on the module's device)."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def activation_layer(activation_name="relu", emb_dim=None):
+    """layers.py:45-67: name -> activation module (None for "none")."""
+    if activation_name is None:
+        return None
+    if isinstance(activation_name, str):
+        table = {"sigmoid": nn.Sigmoid, "tanh": nn.Tanh, "relu": nn.ReLU, "leakyrelu": nn.LeakyReLU}
+        key = activation_name.lower()
+        if key == "none":
+            return None
+        if key in table:
+            return table[key]()
+        return None
+    if issubclass(activation_name, nn.Module):
+        return activation_name()
+    raise NotImplementedError("activation function {} is not implemented".format(activation_name))
+
+
+class MLPLayers(nn.Module):
+    """[Dropout, Linear, (BatchNorm1d), activation] per layer; the last layer has neither
+    BatchNorm nor activation; Xavier-normal weights, zero biases (layers.py:7-40)."""
+
+    def __init__(self, layers, dropout=0.0, activation="relu", bn=False):
+        super().__init__()
+        self.layers = layers
+        self.dropout = dropout
+        self.activation = activation
+        self.use_bn = bn
+        mods, self._groups = [], []
+        last = len(layers) - 2
+        for i, (fan_in, fan_out) in enumerate(zip(layers[:-1], layers[1:])):
+            group = {"drop": len(mods)}
+            mods.append(nn.Dropout(p=dropout))
+            group["linear"] = len(mods)
+            mods.append(nn.Linear(fan_in, fan_out))
+            if bn and i != last:
+                group["bn"] = len(mods)
+                mods.append(nn.BatchNorm1d(num_features=fan_out))
+            act = activation_layer(activation, fan_out)
+            if act is not None and i != last:
+                group["act"] = len(mods)
+                mods.append(act)
+            self._groups.append(group)
+        self.mlp_layers = nn.Sequential(*mods)
+        self.apply(self.init_weights)
+
+    def init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            xavier_normal_(module.weight.data)
+            if module.bias is not None:
+                module.bias.data.fill_(0.0)
+
+    # ---- what the fused inference path needs: per-layer (W, b, bn_scale, bn_shift)
+    def folded(self):
+        Ws, bs, scs, shs = [], [], [], []
+        for g in self._groups:
+            lin = self.mlp_layers[g["linear"]]
+            Ws.append(lin.weight.detach())
+            bs.append(lin.bias.detach())
+            if "bn" in g:
+                sc, sh = fold_batchnorm(self.mlp_layers[g["bn"]])
+            else:
+                sc = sh = None
+            scs.append(sc)
+            shs.append(sh)
+        return Ws, bs, scs, shs
+
+    def fusable(self):
+        """True when every activation is ReLU (the only one the GEMM epilogue implements)."""
+        return all(("act" not in g) or isinstance(self.mlp_layers[g["act"]], nn.ReLU) for g in self._groups)
+
+    def forward(self, input_feature):
+        x = input_feature
+        if x.dim() != 2:
+            x = x.reshape(-1, x.shape[-1])
+        for g in self._groups:
+            mods = self.mlp_layers
+            if self.training and self.dropout > 0:
+                x = mods[g["drop"]](x)
+            lin = mods[g["linear"]]
+            relu_mod = mods[g["act"]] if "act" in g else None
+            is_relu = isinstance(relu_mod, nn.ReLU)
+            if "bn" in g:
+                bn = mods[g["bn"]]
+                if self.training:
+                    x = _LinearAct.apply(x, lin.weight, lin.bias, False)
+                    x = bn(x)                      # batch statistics + running-stat update (torch)
+                    if relu_mod is not None:
+                        x = relu_mod(x)
+                    continue
+                if not torch.is_grad_enabled() and (relu_mod is None or is_relu):
+                    sc, sh = fold_batchnorm(bn)
+                    x = ops.linear_forward(x, lin.weight.detach(), lin.bias.detach(), sc, sh, relu=is_relu)
+                    continue
+                x = _LinearAct.apply(x, lin.weight, lin.bias, False)
+                x = bn(x)
+                if relu_mod is not None:
+                    x = relu_mod(x)
+                continue
+            fuse = relu_mod is None or is_relu
+            x = _LinearAct.apply(x, lin.weight, lin.bias, bool(is_relu and fuse))
+            if relu_mod is not None and not is_relu:
+                x = relu_mod(x)
+        return x.reshape(*input_feature.shape[:-1], x.shape[-1])
+
+
+def kmeans(samples, num_clusters, num_iters=10):
+    """layers.py:69-82: sklearn KMeans on the host (k-means++ from numpy's global RNG), centres
+    returned on the samples' device.  Runs once per level per training run; the sklearn call is the
+    reference's own behaviour and its result is not bit-pinned."""
+    from sklearn.cluster import KMeans
+    x = samples.detach().cpu().numpy()
+    cluster = KMeans(n_clusters=num_clusters, max_iter=num_iters).fit(x)
+    return torch.from_numpy(cluster.cluster_centers_).to(samples.device)
+
+
+@torch.no_grad()
+def sinkhorn_algorithm(distances, epsilon, sinkhorn_iterations):
+    """layers.py:85-108 on an already centred [B, K] matrix: returns Q (fp64, rows sum to 1).
+
+    Kept for API parity (the quantiser itself calls the fused lcrec_sinkhorn_assign, which never
+    materialises Q on the host side).  Runs as device tensor ops in the reference's order."""
+    if not distances.is_cuda:
+        raise ops._lib.LcrecError("sinkhorn_algorithm expects a device tensor (lcrec_amd has no CPU path)")
+    Q = torch.exp(-distances / epsilon)
+    B, K = Q.shape
+    Q /= Q.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    for _ in range(sinkhorn_iterations):
+        Q /= torch.sum(Q, dim=1, keepdim=True)
+        Q /= B
+        Q /= torch.sum(Q, dim=0, keepdim=True)
+        Q /= K
+    Q *= B
+    return Q

@@ -236,6 +236,36 @@ def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps):
     _lib.check(rc, "lcrec_ema_update")
 
 
+def collision_groups(idx, ks, want_groups=True):
+    """Tuple collisions of an int64 [n, L] index matrix (trainer.py:139-150, generate_indices.py:18-42).
+
+    Returns dict(unique, max_count, collision_rate) and, with want_groups, `groups`: a list of
+    item-id lists in get_collision_item's order (first occurrence of the tuple; ids ascending)."""
+    lib = _lib.load()
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 2):
+        raise _lib.LcrecError("idx must be an int64 [n, L] device tensor")
+    idx = idx.contiguous()
+    n, L = idx.shape
+    dev = idx.device
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    members = torch.empty(max(n, 1), dtype=torch.int64, device=dev) if want_groups else None
+    offsets = torch.empty(n // 2 + 2, dtype=torch.int64, device=dev) if want_groups else None
+    karr = _ints(ks)
+    with torch.cuda.device(dev):
+        nbytes = lib.lcrec_collision_groups_workspace(n, L)
+        ws = _workspace(nbytes, dev)
+        rc = lib.lcrec_collision_groups(_ptr(idx), n, L, karr, _ptr(members), _ptr(offsets), _ptr(counters), _ptr(ws),
+                                        ws.numel(), _stream_ptr())
+    _lib.check(rc, "lcrec_collision_groups")
+    c = counters.tolist()
+    out = {"unique": c[0], "max_count": c[3], "collision_rate": (n - c[0]) / n if n else 0.0}
+    if want_groups:
+        offs = offsets[: c[1] + 1].tolist()
+        mem = members[: c[2]].tolist()
+        out["groups"] = [mem[offs[g]:offs[g + 1]] for g in range(c[1])]
+    return out
+
+
 def trace_enable(on=True):
     """Bracket every kernel launch with hipEvents (include/lcrec.h, lcrec_trace_enable)."""
     _lib.check(_lib.load().lcrec_trace_enable(int(bool(on))), "lcrec_trace_enable")

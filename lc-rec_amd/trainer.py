@@ -1,0 +1,265 @@
+"""RQ-VAE training harness -- host-side mirror of the reference's index/trainer.py
+(Trainer :14-251) and of index_improve/trainer.py's additions (use_ema forward, codebook
+utilisation in the evaluation line).  Behaviour kept on purpose, because people and scripts
+depend on it:
+  * `train loss` / `reconstruction loss` are SUMS over the epoch's batches (trainer.py:122-125);
+  * best_loss is only compared on evaluation epochs (:207), cur_eval_step is counted but never
+    stops training (:189,213,217);
+  * checkpoint dict keys, file names and the newest-N + best-N retention (:154-172, :231-247);
+  * log line formats (:174-184, :221-230).
+What differs is where the work happens: batches are slices of an HBM-resident matrix, the step
+runs the HIP kernels through the module API, and the collision rate is a device sort
+(lcrec_collision_groups) instead of a Python string set.
+"""
+import heapq
+import logging
+import os
+from time import time
+
+import numpy as np
+import torch
+from torch import optim
+from tqdm import tqdm
+
+from . import ops
+from .utils import delete_file, ensure_dir, get_local_time, set_color
+
+
+def linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
+    """The multiplier the reference gets from transformers.get_linear_schedule_with_warmup
+    (trainer.py:85-87): ramp 0 -> 1 over the warm-up, then linearly to 0 at num_training_steps."""
+    def factor(step):
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch)
+
+
+def constant_schedule_with_warmup(optimizer, num_warmup_steps, last_epoch=-1):
+    """transformers.get_constant_schedule_with_warmup (trainer.py:89-90): ramp 0 -> 1, then 1."""
+    def factor(step):
+        if step < num_warmup_steps:
+            return float(step) / float(max(1.0, num_warmup_steps))
+        return 1.0
+    return optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch)
+
+
+class CheckpointKeeper:
+    """Retention rule of trainer.py:231-247: keep the `limit` newest evaluation checkpoints plus the
+    `limit` with the lowest collision rate; a file leaves the disk when it is in neither set."""
+
+    def __init__(self, limit, remove=delete_file):
+        self.limit = limit
+        self.remove = remove
+        self.best = []      # min-heap of (-collision_rate, path): root = worst of the kept best
+        self.newest = []    # FIFO
+
+    def add(self, collision_rate, path):
+        entry = (-collision_rate, path)
+        if len(self.newest) < self.limit:
+            self.newest.append(entry)
+            heapq.heappush(self.best, entry)
+            return
+        oldest = self.newest.pop(0)
+        self.newest.append(entry)
+        if collision_rate < -self.best[0][0]:
+            dropped = heapq.heappop(self.best)
+            heapq.heappush(self.best, entry)
+            if dropped not in self.newest:
+                self.remove(dropped[1])
+        if oldest not in self.best:
+            self.remove(oldest[1])
+
+
+class Trainer(object):
+
+    def __init__(self, args, model, data_num):
+        self.args = args
+        self.model = model
+        self.logger = logging.getLogger()
+
+        self.lr = args.lr
+        self.learner = args.learner
+        self.lr_scheduler_type = args.lr_scheduler_type
+        self.weight_decay = args.weight_decay
+        self.epochs = args.epochs
+        self.warmup_steps = args.warmup_epochs * data_num
+        self.max_steps = args.epochs * data_num
+
+        self.save_limit = args.save_limit
+        self.keeper = CheckpointKeeper(self.save_limit)
+        self.eval_step = min(args.eval_step, self.epochs)
+        self.device = torch.device(args.device)
+        self.ckpt_dir = os.path.join(args.ckpt_dir, "{}".format(get_local_time()))
+        ensure_dir(self.ckpt_dir)
+
+        self.best_loss = np.inf
+        self.best_collision_rate = np.inf
+        self.best_loss_ckpt = "best_loss_model.pth"
+        self.best_collision_ckpt = "best_collision_model.pth"
+        self.use_ema = getattr(args, "ema_decay", None) is not None
+        self.optimizer = self._build_optimizer()
+        self.scheduler = self._get_scheduler()
+        self.model = self.model.to(self.device)
+        self.dist = None            # set by lcrec_amd.dist.attach() for item-sharded data parallel
+
+    # reference attribute names, for scripts that poke at them
+    @property
+    def best_save_heap(self):
+        return self.keeper.best
+
+    @property
+    def newest_save_queue(self):
+        return self.keeper.newest
+
+    def _build_optimizer(self):
+        params = self.model.parameters()
+        name = self.learner.lower()
+        lr, wd = self.lr, self.weight_decay
+        if name == "adam":
+            return optim.Adam(params, lr=lr, weight_decay=wd)
+        if name == "sgd":
+            return optim.SGD(params, lr=lr, weight_decay=wd)
+        if name == "adagrad":
+            opt = optim.Adagrad(params, lr=lr, weight_decay=wd)
+            for state in opt.state.values():
+                for k, v in state.items():
+                    if torch.is_tensor(v):
+                        state[k] = v.to(self.device)
+            return opt
+        if name == "rmsprop":
+            return optim.RMSprop(params, lr=lr, weight_decay=wd)
+        if name == "adamw":
+            return optim.AdamW(params, lr=lr, weight_decay=wd)
+        self.logger.warning("Received unrecognized optimizer, set default Adam optimizer")
+        return optim.Adam(params, lr=lr)
+
+    def _get_scheduler(self):
+        if self.lr_scheduler_type.lower() == "linear":
+            return linear_schedule_with_warmup(self.optimizer, self.warmup_steps, self.max_steps)
+        return constant_schedule_with_warmup(self.optimizer, self.warmup_steps)
+
+    def _check_nan(self, loss):
+        if torch.isnan(loss):
+            raise ValueError("Training loss is nan")
+
+    def _train_epoch(self, train_data, epoch_idx):
+        self.model.train()
+        total_loss = torch.zeros((), dtype=torch.float64, device=self.device)
+        total_recon = torch.zeros((), dtype=torch.float64, device=self.device)
+        iter_data = tqdm(train_data, total=len(train_data), ncols=100, desc=set_color(f"Train {epoch_idx}", "pink"),
+                         disable=not self._is_main())
+        for data in iter_data:
+            data = data.to(self.device)
+            self.optimizer.zero_grad()
+            if self.use_ema:
+                out, rq_loss, _ = self.model(data, use_ema=True)
+            else:
+                out, rq_loss, _ = self.model(data)
+            loss, loss_recon = self.model.compute_loss(out, rq_loss, xs=data)
+            self._check_nan(loss)
+            loss.backward()
+            if self.dist is not None:
+                self.dist.reduce_gradients(self.model, n_local=data.shape[0])
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+            self.optimizer.step()
+            self.scheduler.step()
+            # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step
+            total_loss += loss.detach().double()
+            total_recon += loss_recon.detach().double()
+        return total_loss.item(), total_recon.item()
+
+    @torch.no_grad()
+    def _valid_epoch(self, valid_data):
+        self.model.eval()
+        iter_data = tqdm(valid_data, total=len(valid_data), ncols=100, desc=set_color("Evaluate   ", "pink"),
+                         disable=not self._is_main())
+        chunks = []
+        for data in iter_data:
+            data = data.to(self.device)
+            indices = self.model.get_indices(data)
+            chunks.append(indices.view(-1, indices.shape[-1]))
+        indices = torch.cat(chunks)
+        if self.dist is not None:
+            indices = self.dist.gather_rows(indices)
+        ks = [q.n_e for q in self.model.rq.vq_layers]
+        num_sample = indices.shape[0]
+        unique = ops.collision_groups(indices, ks, want_groups=False)["unique"]
+        return (num_sample - unique) / num_sample
+
+    def _get_codebook_utilization(self):
+        """index_improve/trainer.py:162-171."""
+        try:
+            stats = self.model.get_codebook_usage()
+            return np.mean([s["utilization"] for s in stats]), stats
+        except AttributeError:
+            return None, None
+
+    def _save_checkpoint(self, epoch, collision_rate=1, ckpt_file=None):
+        ckpt_path = os.path.join(self.ckpt_dir, ckpt_file) if ckpt_file \
+            else os.path.join(self.ckpt_dir, "epoch_%d_collision_%.4f_model.pth" % (epoch, collision_rate))
+        if self._is_main():
+            state = {
+                "args": self.args,
+                "epoch": epoch,
+                "best_loss": self.best_loss,
+                "best_collision_rate": self.best_collision_rate,
+                "state_dict": self.model.state_dict(),
+                "optimizer": self.optimizer.state_dict(),
+            }
+            torch.save(state, ckpt_path, pickle_protocol=4)
+            self.logger.info(set_color("Saving current", "blue") + f": {ckpt_path}")
+        return ckpt_path
+
+    def _generate_train_loss_output(self, epoch_idx, s_time, e_time, loss, recon_loss):
+        out = (set_color("epoch %d training", "green") + " [" + set_color("time", "blue") + ": %.2fs, ") \
+            % (epoch_idx, e_time - s_time)
+        out += set_color("train loss", "blue") + ": %.4f" % loss
+        out += ", "
+        out += set_color("reconstruction loss", "blue") + ": %.4f" % recon_loss
+        return out + "]"
+
+    def _is_main(self):
+        return self.dist is None or self.dist.rank == 0
+
+    def fit(self, data):
+        cur_eval_step = 0
+        for epoch_idx in range(self.epochs):
+            t0 = time()
+            train_loss, train_recon_loss = self._train_epoch(data, epoch_idx)
+            t1 = time()
+            self.logger.info(self._generate_train_loss_output(epoch_idx, t0, t1, train_loss, train_recon_loss))
+
+            if (epoch_idx + 1) % self.eval_step == 0:
+                v0 = time()
+                collision_rate = self._valid_epoch(data)
+                avg_util, usage = self._get_codebook_utilization() if self.use_ema else (None, None)
+
+                if train_loss < self.best_loss:
+                    self.best_loss = train_loss
+                    self._save_checkpoint(epoch=epoch_idx, ckpt_file=self.best_loss_ckpt)
+                if collision_rate < self.best_collision_rate:
+                    self.best_collision_rate = collision_rate
+                    cur_eval_step = 0
+                    self._save_checkpoint(epoch_idx, collision_rate=collision_rate, ckpt_file=self.best_collision_ckpt)
+                else:
+                    cur_eval_step += 1
+
+                v1 = time()
+                if avg_util is None:
+                    line = (set_color("epoch %d evaluating", "green") + " [" + set_color("time", "blue") + ": %.2fs, "
+                            + set_color("collision_rate", "blue") + ": %f]") % (epoch_idx, v1 - v0, collision_rate)
+                else:   # index_improve/trainer.py:239-253
+                    line = (set_color("epoch %d evaluating", "green") + " [" + set_color("time", "blue") + ": %.2fs, "
+                            + set_color("collision_rate", "blue") + ": %.4f") % (epoch_idx, v1 - v0, collision_rate)
+                    line += ", " + set_color("codebook_utilization", "blue") + ": %.4f" % avg_util
+                    for s in usage:
+                        line += (f"\n  Quantizer {s['quantizer_id']}: {s['utilization']:.4f} "
+                                 f"({s['used_codes']}/{s['total_codes']})")
+                    line += "]"
+                self.logger.info(line)
+
+                ckpt_path = self._save_checkpoint(epoch_idx, collision_rate=collision_rate)
+                if self._is_main():
+                    self.keeper.add(collision_rate, ckpt_path)
+        return self.best_loss, self.best_collision_rate

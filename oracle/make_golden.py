@@ -19,6 +19,7 @@ import copy
 import hashlib
 import io
 import json
+import logging
 import os
 import sys
 import tempfile
@@ -320,6 +321,174 @@ def fixture_encoder(ref, manifest):
             "latent_abs_max": float(np.abs(lat.numpy()).max())}
 
 
+# --------------------------------------------------------------------------- F6
+def fixture_generate(ref, manifest):
+    """Run the reference's generate_indices.py itself (a module-level script with hard-coded paths,
+    :44-49): its text is read, the four path/device assignments and the torch.load call are
+    substituted, and it is exec'd in a scratch directory.  Nothing of it is stored: only its output."""
+    from oracle import generate_ref
+    import argparse as _ap
+    src = open(os.path.join(REF, "index", "generate_indices.py")).read()
+    for seed in range(600, 640):
+        x = gi.toy_items(seed)
+        torch.manual_seed(seed)
+        kw = dict(num_emb_list=[48, 48, 48], e_dim=16, layers=[64, 32], dropout_prob=0.0, bn=False, loss_type="mse",
+                  quant_loss_weight=1.0, kmeans_init=False, kmeans_iters=10, sk_epsilons=[0.0, 0.0, 0.0], sk_iters=50)
+        model = ref["rqvae"].RQVAE(in_dim=128, **kw)
+        model.eval()
+        with torch.no_grad():
+            resid = model.encoder(t(x))
+            g = torch.Generator().manual_seed(seed)
+            for l in range(3):
+                cb = resid[torch.randperm(len(resid), generator=g)[:48]].clone()
+                model.rq.vq_layers[l].embedding.weight.data.copy_(cb)
+                resid = resid - cb[torch.argmin(torch_ref.distances(resid, cb), -1)]
+        with tempfile.TemporaryDirectory() as tmp:
+            npy = os.path.join(tmp, "Toy.emb.npy")
+            np.save(npy, x)
+            args = _ap.Namespace(data_path=npy, num_workers=0, **kw)
+            ckpt = os.path.join(tmp, "toy.pth")
+            torch.save({"args": args, "epoch": 0, "best_loss": 0.0, "best_collision_rate": 0.0,
+                        "state_dict": model.state_dict(), "optimizer": {}}, ckpt, pickle_protocol=4)
+            patched = src.replace('ckpt_path = "/zhengbowen/rqvae_ckpt/xxxx"', f'ckpt_path = {ckpt!r}')
+            patched = patched.replace('output_dir = f"/zhengbowen/data/{dataset}/"', f'output_dir = {tmp + "/"!r}')
+            patched = patched.replace('device = torch.device("cuda:0")', 'device = torch.device("cpu")')
+            patched = patched.replace("torch.load(ckpt_path, map_location=torch.device('cpu'))",
+                                      "torch.load(ckpt_path, map_location=torch.device('cpu'), weights_only=False)")
+            assert patched != src
+            buf = io.StringIO()
+            cwd = os.getcwd()
+            os.chdir(os.path.join(REF, "index"))
+            try:
+                with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                    exec(compile(patched, "generate_indices(ref)", "exec"), {"__name__": "__ref_generate__"})
+            finally:
+                os.chdir(cwd)
+            text = open(os.path.join(tmp, "Games.index.json")).read()
+        lines = buf.getvalue().splitlines()
+        rounds = [int(s) for s in lines if s.strip().isdigit()]
+        sd = {k: v.numpy() for k, v in model.state_dict().items()}
+        names = gi.state_dict_names(3, False, 3)
+        Ws = [sd[n + ".weight"] for n in names["encoder"]]
+        bs = [sd[n + ".bias"] for n in names["encoder"]]
+        cbs = [sd[n] for n in names["codebooks"]]
+        idx_o, hist_o, text_o = generate_ref.run(x, Ws, bs, cbs)
+        same = text_o == text
+        print(f"  F6 seed {seed}: reference rounds {rounds}, oracle rounds {hist_o}, identical={same}", flush=True)
+        if not same:
+            continue
+        ref_idx = np.asarray([[int(tok[3:-1]) for tok in toks] for toks in json.loads(text).values()], dtype=np.int16)
+        arrays = {"sd__" + k: v for k, v in sd.items()}
+        name = save("f6_generate.npz", idx=ref_idx, groups_per_round=np.asarray(rounds, dtype=np.int64),
+                    json_text=np.frombuffer(text.encode(), dtype=np.uint8), **arrays)
+        manifest["fixtures"][name] = {
+            "pins": "generate_indices.py:77-145 end to end (.index.json bytes, per-round group counts, 20-round cap, "
+                    "forced sk_epsilon rule)", "inputs": f"golden_inputs.toy_items({seed}); state dict stored (sd__*)",
+            "model": dict(in_dim=128, **kw), "seed": seed, "json_sha256": hashlib.sha256(text.encode()).hexdigest(),
+            "oracle_pipeline_bytes_identical": True, "rounds": rounds,
+            "seeds_tried_before": seed - 600,
+            "c_oracle_idx_mismatch_rows": 0}
+        return
+    raise RuntimeError("no seed in 600..639 gave byte-identical output between reference and oracle pipeline")
+
+
+# --------------------------------------------------------------------------- F7
+def fixture_trainer(manifest):
+    """Trainer behaviour that is host logic: checkpoint schema and file names, the newest/best retention
+    walk, HF scheduler multipliers, CLI defaults and the type=bool quirk."""
+    import argparse as _ap
+    import importlib
+    load_reference("index")
+    trainer_mod = importlib.import_module("trainer")
+    main_src = open(os.path.join(REF, "index", "main.py")).read()
+    ns = {"__name__": "__ref_main__"}
+    exec(compile(main_src, "main(ref)", "exec"), ns)           # defines parse_args; the __main__ block is skipped
+    argv0 = sys.argv
+    try:
+        sys.argv = ["main.py"]
+        defaults = vars(ns["parse_args"]())
+        sys.argv = ["main.py", "--bn", "False", "--kmeans_init", "False", "--sk_epsilons", "0.0", "0.003"]
+        quirk = vars(ns["parse_args"]())
+    finally:
+        sys.argv = argv0
+    out = {"cli_defaults": defaults, "cli_bool_quirk": {"bn": quirk["bn"], "kmeans_init": quirk["kmeans_init"],
+                                                        "sk_epsilons": quirk["sk_epsilons"]}}
+
+    from transformers import get_constant_schedule_with_warmup, get_linear_schedule_with_warmup
+    sched = {}
+    for warm, total in ((0, 10), (2, 10), (5, 5), (3, 20)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        o1 = torch.optim.SGD([p], lr=1.0)
+        s1 = get_linear_schedule_with_warmup(optimizer=o1, num_warmup_steps=warm, num_training_steps=total)
+        o2 = torch.optim.SGD([p], lr=1.0)
+        s2 = get_constant_schedule_with_warmup(optimizer=o2, num_warmup_steps=warm)
+        lin, con = [s1.get_last_lr()[0]], [s2.get_last_lr()[0]]
+        for _ in range(total + 3):
+            o1.step(); s1.step(); o2.step(); s2.step()
+            lin.append(s1.get_last_lr()[0]); con.append(s2.get_last_lr()[0])
+        sched[f"{warm},{total}"] = {"linear": lin, "constant": con}
+    out["lr_multipliers"] = sched
+
+    # retention walk + checkpoint schema through the reference Trainer with scripted epochs
+    rates = [0.30, 0.25, 0.27, 0.10, 0.40, 0.12, 0.50, 0.05, 0.60, 0.61, 0.02, 0.70]
+    losses = [9.0, 8.0, 8.5, 7.0, 7.5, 6.0, 6.5, 6.2, 5.0, 5.5, 5.2, 4.0]
+    with tempfile.TemporaryDirectory() as tmp:
+        args = _ap.Namespace(lr=1e-3, learner="AdamW", lr_scheduler_type="linear", weight_decay=1e-4, epochs=len(rates),
+                             warmup_epochs=1, save_limit=3, eval_step=1, device="cpu", ckpt_dir=tmp)
+        ref = load_reference("index")
+        trainer_mod = importlib.import_module("trainer")
+        model = ref["rqvae"].RQVAE(in_dim=32, num_emb_list=[8, 8], e_dim=16, layers=[24], bn=True, kmeans_init=False,
+                                   sk_epsilons=[0.0, 0.0])
+
+        walk = []
+
+        class Scripted(trainer_mod.Trainer):
+            def _train_epoch(self, data, epoch_idx):
+                return losses[epoch_idx], losses[epoch_idx] / 2
+
+            def _valid_epoch(self, data):
+                e = len(walk)
+                return rates[e]
+
+            def _save_checkpoint(self, epoch, collision_rate=1, ckpt_file=None):
+                path = super()._save_checkpoint(epoch, collision_rate=collision_rate, ckpt_file=ckpt_file)
+                return path
+
+        tr = Scripted(args, model, data_num=4)
+        # the directory listing after every evaluation epoch: snapshot at the start of the NEXT
+        # epoch's _valid_epoch, and once more after fit() returns
+        snapshots = []
+        base_valid = Scripted._valid_epoch
+
+        def valid_and_snapshot(self, data):
+            if walk:
+                snapshots.append(sorted(os.listdir(self.ckpt_dir)))
+            r = base_valid(self, data)
+            walk.append(r)
+            return r
+
+        Scripted._valid_epoch = valid_and_snapshot
+        logging.disable(logging.CRITICAL)
+        try:
+            best = tr.fit(None)
+        finally:
+            logging.disable(logging.NOTSET)
+        snapshots.append(sorted(os.listdir(tr.ckpt_dir)))
+        ck = torch.load(os.path.join(tr.ckpt_dir, "best_collision_model.pth"), weights_only=False)
+        schema = {"keys": sorted(ck), "args_type": type(ck["args"]).__name__,
+                  "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in ck["state_dict"].items()},
+                  "optimizer_keys": sorted(ck["optimizer"]), "epoch": ck["epoch"],
+                  "best_collision_rate": ck["best_collision_rate"], "best_loss": ck["best_loss"]}
+    out["retention"] = {"save_limit": 3, "collision_rates": rates, "train_losses": losses,
+                        "files_after_each_eval": snapshots, "fit_returns": [best[0], best[1]]}
+    out["checkpoint_schema"] = schema
+    with open(os.path.join(OUT, "f7_trainer_host_logic.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True, default=str)
+    manifest["fixtures"]["f7_trainer_host_logic.json"] = {
+        "pins": "trainer.py:154-172 checkpoint schema/file names, :231-247 retention, :83-92 scheduler multipliers "
+                "(transformers), main.py:14-49 CLI defaults and the type=bool quirk"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -340,6 +509,12 @@ def main():
         if want is None or name in want:
             print("generating", name, flush=True)
             fn()
+    if want is None or "generate" in want:
+        print("generating generate", flush=True)
+        fixture_generate(load_reference("index"), manifest)
+    if want is None or "trainer" in want:
+        print("generating trainer", flush=True)
+        fixture_trainer(manifest)
     if want is None or "ema" in want:
         print("generating ema", flush=True)
         fixture_ema(manifest)

@@ -98,3 +98,15 @@ def state_dict_names(n_layers, bn, levels):
                    for part in ("encoder", "decoder")} if bn else {}
     names["codebooks"] = [f"rq.vq_layers.{l}.embedding.weight" for l in range(levels)]
     return names
+
+
+# ---------------------------------------------------------------- F6: index generation end to end
+def toy_items(seed, n=3000, d=128):
+    """Clustered toy embeddings with a few exact duplicates (items that can never be separated)."""
+    r = rs(seed)
+    centres = f32(r.standard_normal((400, d)))
+    x = f32(centres[r.randint(0, 400, size=n)] + 0.08 * r.standard_normal((n, d)))
+    x[17] = x[5]
+    x[1200] = x[5]
+    x[2999] = x[2998]
+    return x

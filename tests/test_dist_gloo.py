@@ -1,0 +1,92 @@
+"""CPU, world_size 2, gloo: the multi-GPU plumbing of lc-rec_amd/dist.py (what runs over RCCL on
+the 8-GPU node) -- sharding, gradient all-reduce weighting, row gathers, loader slices."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import argparse
+    from lcrec_amd import dist as ldist
+    from lcrec_amd.datasets import DeviceLoader
+    args = argparse.Namespace(device="cpu")
+    ctx = ldist.init_from_env(args, backend="gloo")
+    assert ctx.enabled and ctx.rank == rank and ctx.world_size == world and ldist.current() is ctx
+
+    # ---- gradient all-reduce = gradient of the global-batch mean loss, also with uneven shards
+    torch.manual_seed(0)
+    model = torch.nn.Linear(6, 3)
+    x = torch.randn(11, 6)
+    y = torch.randn(11, 3)
+    ref = torch.nn.Linear(6, 3)
+    ref.load_state_dict(model.state_dict())
+    torch.nn.functional.mse_loss(ref(x), y).backward()
+    lo, hi = (0, 7) if rank == 0 else (7, 11)
+    torch.nn.functional.mse_loss(model(x[lo:hi]), y[lo:hi]).backward()
+    ctx.reduce_gradients(model, n_local=hi - lo)
+    for p, q in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)
+
+    # ---- row gathers keep rank order with unequal counts
+    rows = torch.arange((3 if rank == 0 else 5) * 2, dtype=torch.int64).view(-1, 2) + 100 * rank
+    allrows = ctx.gather_rows(rows)
+    assert allrows.shape == (8, 2) and allrows[0, 0] == 0 and allrows[3, 0] == 100
+    both, (a, b) = ctx.gather_rows_with_slice(rows.float())
+    assert (a, b) == ((0, 3) if rank == 0 else (3, 8)) and torch.equal(both[a:b], rows.float())
+
+    # ---- statistics all-reduce and broadcast
+    cnt = torch.full((4,), float(rank + 1))
+    tot = torch.full((4, 2), float(rank + 1))
+    ctx.all_reduce_sum_(cnt, tot)
+    assert torch.all(cnt == 3) and torch.all(tot == 3)
+    t = torch.full((3,), float(rank))
+    ctx.broadcast_(t, src=0)
+    assert torch.all(t == 0)
+
+    # ---- loader: every rank walks the same global batch and keeps its contiguous slice
+    data = torch.arange(50, dtype=torch.float32).view(25, 2)
+    torch.manual_seed(5)
+    mine = list(DeviceLoader(data, batch_size=8, shuffle=True, device="cpu", rank=rank, world_size=world))
+    torch.manual_seed(5)
+    full = list(DeviceLoader(data, batch_size=8, shuffle=True, device="cpu"))
+    for part, whole in zip(mine, full):
+        per = (whole.shape[0] + world - 1) // world
+        assert torch.equal(part, whole[rank * per:(rank + 1) * per])
+    assert ldist.shard_range(10, rank, world) == ((0, 5) if rank == 0 else (5, 10))
+    assert ldist.shard_range(7, 1, 4) == (2, 4) and ldist.shard_range(3, 3, 4) == (3, 3)
+    with open(os.path.join(tmp, f"ok{rank}"), "w") as fh:
+        fh.write("ok")
+    ldist.shutdown(ctx)
+
+
+def test_dist_collectives_world_size_2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_single_process_context_is_inert():
+    from lcrec_amd import dist as ldist
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    ctx = ldist.init_from_env(None)
+    assert not ctx.enabled and ctx.world_size == 1
+    t = torch.ones(3)
+    assert ctx.gather_rows(t) is t
+    ctx.reduce_gradients(torch.nn.Linear(2, 2))
+    ctx.barrier()

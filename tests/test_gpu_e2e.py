@@ -1,0 +1,122 @@
+"""End to end on the MI355X: CLI training run -> checkpoint files -> index generation -> .index.json."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _toy_npy(path, n=600, d=64, seed=3):
+    rs = np.random.RandomState(seed)
+    centres = rs.standard_normal((40, d)).astype(np.float32)
+    x = centres[rs.randint(0, 40, size=n)] + 0.05 * rs.standard_normal((n, d)).astype(np.float32)
+    x[10] = x[3]          # exact duplicates can never be separated (generate_indices.py:108 comment)
+    x[11] = x[3]
+    np.save(path, x.astype(np.float32))
+    return x
+
+
+def test_cli_train_then_generate(hip, tmp_path):
+    from lcrec_amd import generate_indices as gen
+    from lcrec_amd import main as cli
+    data_path = str(tmp_path / "Toy.emb-test-td.npy")
+    x = _toy_npy(data_path)
+    ckpt_root = str(tmp_path / "ckpt")
+    best_loss, best_rate = cli.main([
+        "--data_path", data_path, "--ckpt_dir", ckpt_root, "--device", "cuda:0", "--epochs", "6", "--eval_step", "2",
+        "--batch_size", "128", "--layers", "32", "--e_dim", "16", "--num_emb_list", "16", "16", "16",
+        "--sk_epsilons", "0.0", "0.0", "0.003", "--sk_iters", "50", "--warmup_epochs", "1", "--lr_scheduler_type", "linear",
+        "--weight_decay", "1e-4", "--save_limit", "2", "--kmeans_iters", "10"])
+    assert np.isfinite(best_loss) and 0.0 <= best_rate <= 1.0
+    runs = os.listdir(ckpt_root)
+    assert len(runs) == 1
+    files = sorted(os.listdir(os.path.join(ckpt_root, runs[0])))
+    assert "best_loss_model.pth" in files and "best_collision_model.pth" in files
+    assert any(f.startswith("epoch_") and f.endswith("_model.pth") for f in files)
+    ckpt_path = os.path.join(ckpt_root, runs[0], "best_collision_model.pth")
+    ckpt = gen.load_checkpoint(ckpt_path)
+    assert sorted(ckpt) == ["args", "best_collision_rate", "best_loss", "epoch", "optimizer", "state_dict"]
+    assert isinstance(ckpt["args"], argparse.Namespace)
+    assert all(v.dtype == torch.float32 for v in ckpt["state_dict"].values())
+    assert sorted(ckpt["state_dict"]) == sorted([
+        "encoder.mlp_layers.1.weight", "encoder.mlp_layers.1.bias", "encoder.mlp_layers.4.weight",
+        "encoder.mlp_layers.4.bias", "decoder.mlp_layers.1.weight", "decoder.mlp_layers.1.bias",
+        "decoder.mlp_layers.4.weight", "decoder.mlp_layers.4.bias", "rq.vq_layers.0.embedding.weight",
+        "rq.vq_layers.1.embedding.weight", "rq.vq_layers.2.embedding.weight"])
+
+    out_file = str(tmp_path / "out" / "Toy.index.json")
+    stats = gen.generate(ckpt_path, out_file, device="cuda:0", verbose=False)
+    with open(out_file) as fh:
+        text = fh.read()
+    index = json.loads(text)
+    assert list(index) == [str(i) for i in range(len(x))]                     # data.py iterates values positionally
+    for toks in index.values():
+        assert len(toks) == 3 and all(t[0] == "<" and t[1] == "abc"[i] and t[2] == "_" and t[-1] == ">"
+                                      for i, t in enumerate(toks))
+    assert text == json.dumps({int(k): v for k, v in index.items()})          # json.dump's default separators
+    assert index["10"] == index["3"] == index["11"]                            # exact duplicates stay together
+    assert stats["items"] == len(x) and stats["rounds"] <= 20
+
+    # the batched conflict resolution equals the reference's one-forward-per-group loop on the same arithmetic
+    model = gen.build_model_from_args(ckpt["args"], x.shape[1])
+    model.load_state_dict(ckpt["state_dict"])
+    model = model.to("cuda:0").eval()
+    xd = torch.from_numpy(x).to("cuda:0")
+    idx = model.get_indices(xd, use_sk=False)
+    for q in model.rq.vq_layers[:-1]:
+        q.sk_epsilon = 0.0
+    if model.rq.vq_layers[-1].sk_epsilon == 0.0:
+        model.rq.vq_layers[-1].sk_epsilon = 0.003
+    history = []
+    for _ in range(20):
+        rows = [tuple(r) for r in idx.tolist()]
+        if gen.check_collision(rows):
+            break
+        groups = gen.get_collision_item(rows)
+        history.append(len(groups))
+        for g in groups:
+            idx[g] = model.get_indices(xd[g], use_sk=True)
+    assert history == stats["groups_per_round"]
+    assert gen.tokens_for(idx.tolist()) == list(index.values())
+
+
+def test_ema_training_runs_and_reports_utilisation(hip, tmp_path):
+    from lcrec_amd import main as cli
+    data_path = str(tmp_path / "Toy.npy")
+    _toy_npy(data_path, n=512)
+    best_loss, best_rate = cli.main([
+        "--data_path", data_path, "--ckpt_dir", str(tmp_path / "ck"), "--device", "cuda:0", "--epochs", "4",
+        "--eval_step", "2", "--batch_size", "128", "--layers", "32", "--e_dim", "16", "--num_emb_list", "32", "32",
+        "--sk_epsilons", "0.0", "0.0", "--ema_decay", "0.99", "--reset_interval", "3", "--no_kmeans_init"])
+    assert np.isfinite(best_loss) and 0.0 <= best_rate <= 1.0
+
+
+def test_generate_reproduces_reference_index_json_bytes(hip, tmp_path):
+    """tests/golden/f6_generate.npz: the reference's generate_indices.py (run unmodified but for its
+    hard-coded paths) on a collision-heavy toy model -- 20 rounds, 606 -> 52 groups.  The product's
+    batched device flow must emit the same bytes."""
+    import argparse
+    import golden_inputs as gi
+    from lcrec_amd import generate_indices as gen
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "f6_generate.npz"))
+    meta = json.load(open(os.path.join(gold, "manifest.json")))["fixtures"]["f6_generate.npz"]
+    x = gi.toy_items(meta["seed"])
+    npy = str(tmp_path / "Toy.emb.npy")
+    np.save(npy, x)
+    kw = {k: v for k, v in meta["model"].items() if k != "in_dim"}
+    args = argparse.Namespace(data_path=npy, num_workers=0, **kw)
+    sd = {k[4:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd__")}
+    ckpt = str(tmp_path / "toy.pth")
+    torch.save({"args": args, "epoch": 0, "best_loss": 0.0, "best_collision_rate": 0.0, "state_dict": sd,
+                "optimizer": {}}, ckpt, pickle_protocol=4)
+    out = str(tmp_path / "Toy.index.json")
+    stats = gen.generate(ckpt, out, device="cuda:0", verbose=False)
+    assert stats["groups_per_round"] == g["groups_per_round"].tolist()
+    want = bytes(g["json_text"])
+    got = open(out, "rb").read()
+    assert got == want, "index.json differs from the reference's bytes"

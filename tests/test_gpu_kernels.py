@@ -236,3 +236,29 @@ def test_ema_update_matches_reference_fixture(hip, oracle):
     assert np.array_equal(en.cpu().numpy(), g["ema_count1"])
     assert np.array_equal(ew.cpu().numpy(), g["ema_sum1"])
     assert np.array_equal(w.cpu().numpy(), g["codebook1"])
+
+
+@pytest.mark.parametrize("n,Ks", [(5000, [16, 16, 16]), (20000, [256] * 4), (3000, [1024] * 8), (1, [256] * 4), (64, [4])])
+def test_collision_groups_match_reference_helper(hip, n, Ks):
+    """lcrec_collision_groups vs the dict-based helper semantics of generate_indices.py:18-42."""
+    from lcrec_amd import generate_indices as gen
+    rs = _rs(n + len(Ks))
+    L = len(Ks)
+    if L == 8:   # wide tuples (80 bits): force collisions by duplicating rows
+        base = np.stack([rs.randint(0, K, size=n // 3 + 1) for K in Ks], 1)
+        rows = base[rs.randint(0, len(base), size=n)]
+    else:
+        rows = np.stack([rs.randint(0, min(K, 6), size=n) for K in Ks], 1) if n > 64 else \
+            np.stack([rs.randint(0, K, size=n) for K in Ks], 1)
+    rows = rows.astype(np.int64)
+    keys = [tuple(r) for r in rows.tolist()]
+    want_groups = gen.get_collision_item(keys)
+    counts = gen.get_indices_count(keys)
+    got = hip.ops.collision_groups(torch.from_numpy(rows).to("cuda:0"), Ks)
+    assert got["unique"] == len(counts)
+    assert got["max_count"] == max(counts.values())
+    assert got["groups"] == want_groups                       # same order: first occurrence, ids ascending
+    assert abs(got["collision_rate"] - (n - len(counts)) / n) < 1e-15
+    assert gen.check_collision(keys) == (len(want_groups) == 0)
+    rate_only = hip.ops.collision_groups(torch.from_numpy(rows).to("cuda:0"), Ks, want_groups=False)
+    assert rate_only["unique"] == got["unique"] and rate_only["max_count"] == got["max_count"]

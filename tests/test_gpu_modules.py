@@ -1,0 +1,119 @@
+"""Module API (RQVAE / ResidualVectorQuantizer / VectorQuantizer / MLPLayers) on the MI355X
+against the golden vectors produced by the real reference (tests/golden/f4_*, f8_*)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def _tiny(hip, bn):
+    g = np.load(os.path.join(GOLD, f"f4_step_bn{bn}.npz"))
+    model = hip.RQVAE(in_dim=128, num_emb_list=[256] * 4, e_dim=16, layers=[64, 32], dropout_prob=0.0, bn=bool(bn),
+                      loss_type="mse", quant_loss_weight=1.0, beta=0.25, kmeans_init=False, kmeans_iters=100,
+                      sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+    sd = {k[4:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd__")}
+    model.load_state_dict(sd, strict=True)          # same keys, shapes, dtypes as the reference
+    x = torch.from_numpy(gi.f32(gi.rs(400 + bn).standard_normal((256, 128)))).to(DEV)
+    return g, model.to(DEV), x
+
+
+@pytest.mark.parametrize("bn", [0, 1])
+def test_eval_forward_matches_reference(hip, bn):
+    g, model, x = _tiny(hip, bn)
+    model.eval()
+    with torch.no_grad():
+        out, rq_loss, idx = model(x, use_sk=False)
+        loss, recon = model.compute_loss(out, rq_loss, xs=x)
+        idx2 = model.get_indices(x)
+    assert np.array_equal(idx.cpu().numpy(), g["eval_idx"].astype(np.int64))       # bit-exact indices
+    assert np.array_equal(idx2.cpu().numpy(), g["eval_idx"].astype(np.int64))
+    np.testing.assert_allclose(out.cpu().numpy(), g["eval_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rq_loss.item(), float(g["eval_rq_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), float(g["eval_loss_total"]), rtol=1e-5)
+    np.testing.assert_allclose(recon.item(), float(g["eval_loss_recon"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("bn", [0, 1])
+def test_training_steps_match_reference(hip, bn):
+    """trainer.py:111-120 three times: forward (Sinkhorn on the last level), loss, backward,
+    clip 1.0, AdamW, linear warm-up -- against the reference's recorded trajectory."""
+    from lcrec_amd.trainer import linear_schedule_with_warmup
+    g, model, x = _tiny(hip, bn)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    sched = linear_schedule_with_warmup(opt, num_warmup_steps=2, num_training_steps=10)
+    traj = g["trajectory"]
+    for step in range(3):
+        opt.zero_grad()
+        out, rq_loss, idx = model(x)
+        loss, recon = model.compute_loss(out, rq_loss, xs=x)
+        loss.backward()
+        if step == 0:
+            assert np.array_equal(idx.cpu().numpy(), g["train_idx"].astype(np.int64))
+            np.testing.assert_allclose(out.detach().cpu().numpy(), g["train_out"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(loss.item(), float(g["train_loss"]), rtol=1e-5)
+            np.testing.assert_allclose(rq_loss.item(), float(g["train_rq_loss"]), rtol=1e-5)
+            # absolute floor relative to the largest gradient entry of the whole model: the bias of a
+            # Linear that feeds BatchNorm has an exactly-zero gradient, i.e. pure rounding noise
+            gmax = max(np.abs(g[f]).max() for f in g.files if f.startswith("grad__"))
+            for k, p in model.named_parameters():
+                ref = g["grad__" + k]
+                np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * gmax, err_msg=k)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        sched.step()
+        np.testing.assert_allclose([loss.item(), recon.item(), rq_loss.item(), float(gn), sched.get_last_lr()[0]],
+                                   traj[step], rtol=2e-5, err_msg=f"step {step}")
+        if step == 0:
+            for k, v in model.state_dict().items():
+                ref = g["step1__" + k]
+                if np.issubdtype(ref.dtype, np.floating):
+                    np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=1e-4, atol=2e-6, err_msg=k)
+                else:
+                    assert np.array_equal(v.cpu().numpy(), ref), k
+
+
+@pytest.mark.parametrize("name,in_dim,n,bn", [("f8_encode_768_bn0.npz", 768, 2048, False),
+                                              ("f8_encode_768_bn1.npz", 768, 1024, True),
+                                              ("f8_encode_4096_bn0.npz", 4096, 512, False)])
+def test_get_indices_full_size_matches_reference(hip, name, in_dim, n, bn):
+    g = np.load(os.path.join(GOLD, name))
+    dims, Ws, bs, bns, x = gi.encoder_case(in_dim, n, bn=bn)
+    model = hip.RQVAE(in_dim=in_dim, num_emb_list=[256] * 4, e_dim=32, layers=gi.RUN_SH_LAYERS, bn=bn,
+                      kmeans_init=False, sk_epsilons=[0.0] * 4, sk_iters=50)
+    names = gi.state_dict_names(len(Ws), bn, 4)
+    sd = model.state_dict()
+    for l, nme in enumerate(names["encoder"]):
+        sd[nme + ".weight"] = torch.from_numpy(Ws[l])
+        sd[nme + ".bias"] = torch.from_numpy(bs[l])
+    if bn:
+        for l, nme in enumerate(names["bn"]["encoder"]):
+            for k, v in bns[l].items():
+                sd[f"{nme}.{k}"] = torch.from_numpy(v)
+    for l, nme in enumerate(names["codebooks"]):
+        sd[nme] = torch.from_numpy(g["codebooks"][l])
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    xd = torch.from_numpy(x).to(DEV)
+    idx = model.get_indices(xd)
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == (n, 4)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"].astype(np.int64))          # bit-exact vs the reference
+    with torch.no_grad():
+        lat = model.encoder(xd)
+    np.testing.assert_allclose(lat.cpu().numpy(), g["latent"], rtol=1e-5, atol=1e-5)
+    # batch 64 (generate_indices.py:78) gives the same rows: the fma-chain order does not depend on the batch
+    idx64 = torch.cat([model.get_indices(xd[i:i + 64]) for i in range(0, n, 64)])
+    assert torch.equal(idx64, idx)
+
+
+def test_no_cpu_path(hip):
+    model = hip.RQVAE(in_dim=128, num_emb_list=[256] * 2, e_dim=16, layers=[64], sk_epsilons=[0.0, 0.0])
+    with pytest.raises(hip.LcrecError):
+        model.eval().get_indices(torch.zeros(4, 128))

@@ -24,7 +24,7 @@ def manifest():
 def test_manifest_lists_every_fixture_and_hashes_match():
     import hashlib
     m = manifest()
-    files = sorted(f for f in os.listdir(GOLD) if f.endswith(".npz"))
+    files = sorted(f for f in os.listdir(GOLD) if f != "manifest.json")
     assert files == sorted(m["fixtures"])
     for f in files:
         with open(os.path.join(GOLD, f), "rb") as fh:
