@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--items", type=int, default=0, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real multi-GPU run); gloo = rehearsal of the N>1 code path, "
+                         "ranks may then share one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,12 +153,18 @@ def main():
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a MI355X: no HIP device visible (lcrec_amd has no CPU path)")
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        sys.exit(f"LOCAL_RANK {local_rank} but only {ndev} HIP device(s) visible")
+    device = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     import lcrec_amd
     from lcrec_amd import ops
@@ -189,7 +198,7 @@ def main():
     trace = ops.trace_collect()
     ops.trace_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -23,6 +23,8 @@
 // bank-conflict free (16 consecutive rows cover 16 distinct 4-bank slots).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace lcrec {
 
 constexpr int BK = 32;   // K slice per step
@@ -79,7 +81,7 @@ template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
-    int64_t M, int N, int K, int relu, int bn_blocks)
+    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune)
 {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -88,8 +90,36 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int64_t m0 = (int64_t)(blockIdx.x / bn_blocks) * BM;
-    const int n0 = (int)(blockIdx.x % bn_blocks) * BN;
+    // Block -> tile.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD
+    // and its L2), so row panel p is given to XCD p%8 and all column blocks of a panel run there:
+    // the activation panel is fetched into ONE L2 instead of up to eight.  Placement only affects speed.
+    int64_t bm;
+    int bn;
+    if (tune & 1) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int panels = (bm_blocks - xcd + 7) >> 3;
+        if (j >= panels * bn_blocks) return;
+        bm = (int64_t)(j / bn_blocks) * 8 + xcd;
+        bn = j % bn_blocks;
+    } else {
+        bm = blockIdx.x / bn_blocks;
+        bn = blockIdx.x % bn_blocks;
+    }
+    const int64_t m0 = bm * BM;
+    const int n0 = bn * BN;
+    // Co-resident workgroups run the same program and tend to hit their barriers together; distinct
+    // wave priorities let one of them own the MFMA pipe while the others stage.
+    if (tune & 2) {
+        const int pr = (blockIdx.x >> 8) & 3;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    if (tune & 4) {
+        const int ph = (blockIdx.x >> 8) % 3;
+        if (ph == 1) __builtin_amdgcn_s_sleep(20);
+        else if (ph == 2) __builtin_amdgcn_s_sleep(40);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -176,11 +206,12 @@ static int launch_linear(const float *x, int64_t n, int in_dim, const float *W, 
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     const int64_t bm_blocks = (n + BM - 1) / BM;
     const int bn_blocks = (out_dim + BN - 1) / BN;
-    const int64_t grid = bm_blocks * bn_blocks;
+    static const int tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return e ? atoi(e) : 0; }();
+    const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
     hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN>), dim3((unsigned)grid), dim3(256), 0,
-                       stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks);
+                       stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
     return check_launch("linear_fwd_kernel");
 }
 

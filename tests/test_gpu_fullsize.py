@@ -1,0 +1,103 @@
+"""BASELINE.json's full-size configurations on the MI355X, checked through size-independent
+properties (the CPU oracle only sees a sample): batch/chunk invariance, agreement of the fused call
+with the layer-by-layer path, residual algebra, and collision counts against an independent
+device computation."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HIDDEN = [2048, 1024, 512, 256, 128, 64]
+
+
+def _model(in_dim, Ks, e=32, seed=11):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    dims = [in_dim] + HIDDEN + [e]
+    Ws = [torch.randn((dims[l + 1], dims[l]), generator=g, device=DEV) * (2.0 / (dims[l] + dims[l + 1])) ** 0.5
+          for l in range(len(dims) - 1)]
+    bs = [0.01 * torch.randn(dims[l + 1], generator=g, device=DEV) for l in range(len(dims) - 1)]
+    return dims, Ws, bs, g
+
+
+def _codebooks(hip, z, Ks, g):
+    cbs, resid = [], z
+    for K in Ks:
+        cbs.append(resid[torch.randperm(resid.shape[0], generator=g, device=DEV)[:K]].clone())
+        flat, ks = hip.ops.flatten_codebooks(cbs)
+        resid = hip.ops.rq_assign(z, flat, ks, want_resid=True)[3][len(cbs)]
+    return cbs
+
+
+def _encode(hip, x, Ws, bs):
+    z = x
+    for l in range(len(Ws)):
+        z = hip.ops.linear_forward(z, Ws[l], bs[l], relu=l != len(Ws) - 1)
+    return z
+
+
+@pytest.mark.parametrize("name,n,in_dim", [("C3", 1_000_000, 768), ("C2", 16_859, 4096)])
+def test_encode_assign_full_size_properties(hip, oracle, name, n, in_dim):
+    Ks = [256] * 4
+    dims, Ws, bs, g = _model(in_dim, Ks)
+    x = torch.randn((n, in_dim), generator=g, device=DEV)
+    cbs = _codebooks(hip, _encode(hip, x[:8192], Ws, bs), Ks, g)
+    flat, ks = hip.ops.flatten_codebooks(cbs)
+    idx, latent, xq, sse = hip.ops.encode_assign(x, Ws, bs, flat, ks, want_latent=True, want_xq=True, want_sse=True)
+    assert idx.shape == (n, 4) and int(idx.min()) >= 0 and int(idx.max()) < 256
+    # (1) the fused call == the layer-by-layer path (same kernels, different chunking)
+    z = torch.cat([_encode(hip, x[lo:lo + 200_000], Ws, bs) for lo in range(0, n, 200_000)])
+    assert torch.equal(z, latent)
+    idx2, xq2, sse2, resid = hip.ops.rq_assign(z, flat, ks, want_xq=True, want_sse=True, want_resid=True)
+    assert torch.equal(idx2, idx) and torch.equal(xq2, xq)
+    # (2) batch invariance: uneven slices, down to generate_indices.py's batch of 64, give the same rows
+    cuts = [0, 1, 64, 65, 4097, n // 3, n]
+    parts = [hip.ops.encode_assign(x[a:b], Ws, bs, flat, ks)[0] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    assert torch.equal(torch.cat(parts), idx)
+    # (3) residual algebra: z = x_q + final residual up to fp32 rounding of the STE chain
+    err = (z - xq - resid[4]).abs().max().item()
+    assert err <= 4e-6 * max(1.0, z.abs().max().item())
+    # (4) per-level SSE equals the norm of what each level removed
+    for l in range(4):
+        want_sse = ((cbs[l][idx[:, l]].double() - resid[l].double()) ** 2).sum().item()
+        np.testing.assert_allclose(sse[l].item(), want_sse, rtol=1e-6)
+    # (5) a random sample against the CPU oracle, bit for bit
+    pick = torch.randperm(n, generator=g, device=DEV)[:1024].sort().values
+    want = oracle.encode_assign(x[pick].cpu().numpy(), [w.cpu().numpy() for w in Ws], [b.cpu().numpy() for b in bs],
+                                [c.cpu().numpy() for c in cbs], threads=8)
+    assert np.array_equal(idx[pick].cpu().numpy(), want["idx"])
+    assert np.array_equal(latent[pick].cpu().numpy(), want["latent"])
+    # (6) collision statistics against an independent device computation (packed keys + torch.unique)
+    got = hip.ops.collision_groups(idx, ks, want_groups=True)
+    keys = ((idx[:, 0] * 256 + idx[:, 1]) * 256 + idx[:, 2]) * 256 + idx[:, 3]
+    uniq, counts = torch.unique(keys, return_counts=True)
+    assert got["unique"] == uniq.numel() and got["max_count"] == int(counts.max())
+    assert sum(len(gr) for gr in got["groups"]) == int(counts[counts > 1].sum())
+    firsts = [gr[0] for gr in got["groups"]]
+    assert firsts == sorted(firsts) and all(gr == sorted(gr) for gr in got["groups"][:1000])
+
+
+def test_deep_residual_8x1024_properties(hip, oracle):
+    """C5's quantiser shape: 8 levels x 1024 codes do not fit in LDS together -> one launch per level."""
+    n, e, Ks = 300_000, 32, [1024] * 8
+    g = torch.Generator(device=DEV).manual_seed(5)
+    z = torch.randn((n, e), generator=g, device=DEV)
+    cbs = _codebooks(hip, z[:65536].contiguous(), Ks, g)
+    flat, ks = hip.ops.flatten_codebooks(cbs)
+    idx, xq, sse, resid = hip.ops.rq_assign(z, flat, ks, want_xq=True, want_sse=True, want_resid=True)
+    # chaining two 4-level calls (x_q carried over) reproduces the 8-level call exactly
+    fa, ka = hip.ops.flatten_codebooks(cbs[:4])
+    fb, kb = hip.ops.flatten_codebooks(cbs[4:])
+    ia, xa, _, ra = hip.ops.rq_assign(z, fa, ka, want_xq=True, want_resid=True)
+    ib, xb, _, rb = hip.ops.rq_assign(ra[4].contiguous(), fb, kb, want_resid=True, xq_init=xa)
+    assert torch.equal(torch.cat([ia, ib], 1), idx) and torch.equal(xb, xq) and torch.equal(rb[4], resid[8])
+    # SSE decreases level by level on data-scale codebooks; residual algebra holds
+    s = sse.cpu().numpy()
+    assert (np.diff(s) < 0).all()
+    assert (z - xq - resid[8]).abs().max().item() <= 8e-6 * z.abs().max().item()
+    pick = torch.arange(0, n, 293, device=DEV)[:1000]
+    want = oracle.rq_assign(z[pick].cpu().numpy(), [c.cpu().numpy() for c in cbs])
+    assert np.array_equal(idx[pick].cpu().numpy(), want["idx"])
+    # 80-bit tuples: collision statistics vs torch.unique over rows
+    got = hip.ops.collision_groups(idx, ks, want_groups=False)
+    assert got["unique"] == torch.unique(idx, dim=0).shape[0]
