@@ -77,6 +77,53 @@ __device__ __forceinline__ void stage_store(const StageRegs<ROWS> &r, float *lds
     }
 }
 
+// Epilogue of one 32x32 accumulator tile (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) +
+// 4*(lane>>5)): bias / folded BatchNorm / ReLU in registers, then a transpose through a wave-private
+// 32 x LDK patch of LDS so that the global stores are 16 B per lane -- eight lanes write one whole
+// 128-B row segment -- instead of 16 one-dword stores per lane.  The store tail of an MFMA tile is
+// issue-bound, not bandwidth-bound, so a quarter of the store instructions is a quarter of the tail.
+__device__ __forceinline__ void store_tile_32x32(const f32x16 &acc, float *stg, int lane, float *__restrict__ C,
+                                                 int64_t row0, int64_t M, int col0, int N,
+                                                 const float *__restrict__ bias, const float *__restrict__ bn_scale,
+                                                 const float *__restrict__ bn_shift, int relu)
+{
+    const int c = lane & 31, h = lane >> 5;
+    const int col = col0 + c;
+    const bool has_bn = bn_scale != nullptr;
+    float bj = 0.f, sc = 1.f, sh = 0.f;
+    if (col < N) {
+        bj = bias ? bias[col] : 0.f;
+        if (has_bn) { sc = bn_scale[col]; sh = bn_shift[col]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float t = acc[r] + bj;
+        if (has_bn) t = __builtin_fmaf(t, sc, sh);
+        if (relu) t = (t > 0.f) ? t : 0.f;
+        stg[((r & 3) + 8 * (r >> 2) + 4 * h) * LDK + c] = t;
+    }
+    __builtin_amdgcn_wave_barrier();          // LDS ops of one wave execute in order; this pins the compiler
+    const bool vec = (N & 3) == 0;
+    const int c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = (lane >> 3) + 8 * p;
+        const int64_t grow = row0 + row;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + row * LDK + c4);
+        if (grow < M) {
+            float *dst = C + grow * (int64_t)N + col0 + c4;
+            if (vec && col0 + c4 + 3 < N) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (col0 + c4 + t < N) dst[t] = v[t];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
@@ -173,29 +220,222 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
         }
     }
 
-    // epilogue: C/D layout of the 32x32 tile is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue (every wave passed the loop's last barrier after its final LDS operand read, so the
+    // activation tile's LDS can be reused: 32 rows per wave)
+    float *stg = As + wave * 32 * LDK;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (col >= N) continue;
-        const float bj = bias ? bias[col] : 0.f;
-        const bool has_bn = bn_scale != nullptr;
-        const float sc = has_bn ? bn_scale[col] : 1.f;
-        const float sh = has_bn ? bn_shift[col] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
+            store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * TM * 32 + i * 32, M, n0 + wn * TN * 32 + j * 32, N, bias,
+                             bn_scale, bn_shift, relu);
+}
+
+// ------------------------------------------------------------------------------------------
+// Ping-pong variant for the wide layers: 512 threads = 8 waves = two groups of 4; a block
+// computes a 256 x 128 tile, group g owning rows [128g, 128g+128).  The two waves that share a
+// SIMD belong to different groups and ALTERNATE roles every phase (one barrier per phase):
+//
+//   phase 2u   : group 0 issues its global loads for K-tile u+1, then runs K-tile u's 64 MFMAs;
+//                group 1 writes the tile it loaded last phase (A1[u], upper half of W[u+1]) to LDS
+//   phase 2u+1 : group 1 loads (A1[u+1], upper W[u+2]) and runs K-tile u's MFMAs;
+//                group 0 writes (A0[u+1], lower half of W[u+1]) to LDS
+//
+// so each SIMD's MFMA pipe always has exactly one wave in its MFMA phase while its partner stages,
+// instead of co-resident workgroups drifting into the same phase (round 1: pipe idle 20 %).
+// A0/A1 need one LDS buffer each (a group reads and writes its own tile in different phases);
+// W is double-buffered because one group still reads W[u] while the other writes W[u+1].
+// Arithmetic is unchanged: one fma chain per output over k ascending.
+// ------------------------------------------------------------------------------------------
+template <int ROWS, int THREADS>
+struct StageRegsG {
+    static constexpr int ITERS = (ROWS * 4 + THREADS - 1) / THREADS;
+    f32x4 v[ITERS][2];
+};
+
+template <int ROWS, int THREADS>
+__device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const float *__restrict__ src, int64_t row0,
+                                             int64_t rows_total, int K, int k0, int t)
+{
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M) {
-                    float t = acc[i][j][r] + bj;
-                    if (has_bn) t = __builtin_fmaf(t, sc, sh);
-                    if (relu) t = (t > 0.f) ? t : 0.f;
-                    C[row * (int64_t)N + col] = t;
+    for (int it = 0; it < StageRegsG<ROWS, THREADS>::ITERS; ++it) {
+        const int p = t + it * THREADS;
+        const int row = p >> 2, kg = p & 3;
+        const int64_t grow = row0 + row;
+        const int k = k0 + kg * 8;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+        if (row < ROWS && grow < rows_total && k < K) {
+            const f32x4 *g = reinterpret_cast<const f32x4 *>(src + grow * (int64_t)K + k);
+            a = g[0];
+            b = g[1];
+        }
+        r.v[it][0] = a;
+        r.v[it][1] = b;
+    }
+}
+
+template <int ROWS, int THREADS>
+__device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r, float *lds, int t)
+{
+#pragma unroll
+    for (int it = 0; it < StageRegsG<ROWS, THREADS>::ITERS; ++it) {
+        const int p = t + it * THREADS;
+        const int row = p >> 2, kg = p & 3;
+        if (row < ROWS) {
+            const f32x4 a = r.v[it][0], b = r.v[it][1];
+            f32x4 ev = {a[0], a[2], b[0], b[2]};
+            f32x4 od = {a[1], a[3], b[1], b[3]};
+            f32x4 *d = reinterpret_cast<f32x4 *>(lds + row * LDK + kg * 8);
+            d[0] = ev;
+            d[1] = od;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
+    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune)
+{
+    constexpr int GM = 128, BN = 128;           // rows per group, columns per block
+    __shared__ __attribute__((aligned(16))) float As[2][GM * LDK];
+    __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int gt = tid & 255;
+
+    int64_t bm;
+    int bn;
+    if (tune & 1) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int panels = (bm_blocks - xcd + 7) >> 3;
+        if (j >= panels * bn_blocks) return;
+        bm = (int64_t)(j / bn_blocks) * 8 + xcd;
+        bn = j % bn_blocks;
+    } else {
+        bm = blockIdx.x / bn_blocks;
+        bn = blockIdx.x % bn_blocks;
+    }
+    const int64_t m0 = bm * (2 * GM) + grp * GM;   // this group's first row
+    const int n0 = bn * BN;
+    const int64_t w_row0 = n0 + grp * 64;          // the half of the W tile this group stages
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    StageRegsG<GM, 256> ra;     // this group's activation tile
+    StageRegsG<64, 256> rw;     // this group's half of the weight tile
+    const int nk = (K + BK - 1) / BK;
+    float *my_a = As[grp];
+
+    // ---- prologue: W[0] (both halves) and A0[0] into LDS; group 1 leaves (A1[0], upper W[1]) in registers
+    stage_load_g<64, 256>(rw, W, w_row0, N, K, 0, gt);
+    stage_store_g<64, 256>(rw, Ws[0] + grp * 64 * LDK, gt);
+    stage_load_g<GM, 256>(ra, A, m0, M, K, 0, gt);
+    if (grp == 0) {
+        stage_store_g<GM, 256>(ra, my_a, gt);
+    } else {
+        stage_load_g<64, 256>(rw, W, w_row0, N, K, BK, gt);      // upper W[1] (zeros if nk == 1)
+    }
+    __syncthreads();
+
+    const float *a_base = my_a + (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const int w_off = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
+
+    for (int u = 0; u < nk; ++u) {
+        const float *w_base = Ws[u & 1] + w_off;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (grp == half) {
+                // ---- compute role: K-tile u.  Fragment reads of the first half go out first (the partner
+                // wave on this SIMD is still issuing the second half of ITS tile, which hides their
+                // latency), then the global prefetch of the next tiles; the phase barrier sits after the
+                // LAST LDS read, so this wave's remaining 32 MFMAs overlap the partner's next phase.
+                f32x4 af[4][2], wf[4][2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        af[g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + g * 8);
+                        wf[g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + g * 8);
+                    }
                 }
+                if (tune & 8) {
+                } else if (half == 0) {
+                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A0[u+1]
+                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 1) * BK, gt);      // lower W[u+1]
+                } else {
+                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A1[u+1]
+                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 2) * BK, gt);      // upper W[u+2]
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g == 1) {
+#pragma unroll
+                        for (int gg = 2; gg < 4; ++gg) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                af[gg][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + gg * 8);
+                                wf[gg][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + gg * 8);
+                            }
+                        }
+                    }
+                    if (g == 2 && !(tune & 16)) __syncthreads();
+                    if (g == 0 && (tune & 32)) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][q], wf[g][j][q], acc[i][j], 0, 0, 0);
+                }
+            } else {
+                // ---- staging role: registers loaded during this group's last compute phase -> LDS
+                if (tune & 32) __builtin_amdgcn_s_setprio(0);
+                if (tune & 8) {
+                } else if (half == 0) {
+                    // group 1 in phase 2u: A1[u] (needed next phase) and the upper half of W[u+1]
+                    stage_store_g<GM, 256>(ra, my_a, gt);
+                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1] + 64 * LDK, gt);
+                } else {
+                    // group 0 in phase 2u+1: A0[u+1] and the lower half of W[u+1]
+                    stage_store_g<GM, 256>(ra, my_a, gt);
+                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1], gt);
+                }
+                if (!(tune & 16)) __syncthreads();
             }
         }
     }
+
+    // epilogue: each wave transposes through 32 rows of its OWN group's activation buffer (its last
+    // LDS operand read is behind the final mid-phase barrier; the other group never touches it)
+    float *stg = my_a + w4 * 32 * LDK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * 64 + i * 32, M, n0 + wn * 64 + j * 32, N, bias, bn_scale,
+                             bn_shift, relu);
+}
+
+static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *W, const float *b, const float *sc,
+                            const float *sh, int relu, int out_dim, float *y, int tune, hipStream_t stream)
+{
+    const int64_t bm_blocks = (n + 255) / 256;
+    const int bn_blocks = (out_dim + 127) / 128;
+    const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
+    if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
+    TraceScope trace(K_LINEAR_128x128, stream);
+    hipLaunchKernelGGL(linear_fwd_pp_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n, out_dim,
+                       in_dim, relu, bn_blocks, (int)bm_blocks, tune);
+    return check_launch("linear_fwd_pp_kernel");
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -228,6 +468,9 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     if (((uintptr_t)x | (uintptr_t)W) & 15)
         return fail(LCREC_EINVAL, "linear_forward: x and W must be 16-byte aligned");
     if (n == 0) return LCREC_OK;
+    static const int pp = [] { const char *e = getenv("LCREC_GEMM_PP"); return e ? atoi(e) : 0; }();
+    static const int pp_tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return e ? atoi(e) : 0; }();
+    if (out_dim > 64 && pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
     if (out_dim > 64) return launch_linear<2, 2, 2, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
     if (out_dim > 32) return launch_linear<4, 1, 1, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
     return launch_linear<4, 1, 1, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
