@@ -27,6 +27,14 @@
 
 namespace lcrec {
 
+// LCREC_GEMM_TUNE bits other than bit 0 are timing-only ablations (they skip loads, stores or barriers
+// and produce wrong results); they exist only in builds made with -DLCREC_GEMM_ABLATE.
+#ifdef LCREC_GEMM_ABLATE
+#define LCREC_TUNE_MASK 0xff
+#else
+#define LCREC_TUNE_MASK 0x1
+#endif
+
 constexpr int BK = 32;   // K slice per step
 constexpr int LDK = 36;  // padded LDS row length in floats
 
@@ -251,6 +259,7 @@ template <int ROWS, int THREADS>
 struct StageRegsG {
     static constexpr int ITERS = (ROWS * 4 + THREADS - 1) / THREADS;
     f32x4 v[ITERS][2];
+    bool ok[ITERS];
 };
 
 template <int ROWS, int THREADS>
@@ -263,14 +272,14 @@ __device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const
         const int row = p >> 2, kg = p & 3;
         const int64_t grow = row0 + row;
         const int k = k0 + kg * 8;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-        if (row < ROWS && grow < rows_total && k < K) {
-            const f32x4 *g = reinterpret_cast<const f32x4 *>(src + grow * (int64_t)K + k);
-            a = g[0];
-            b = g[1];
-        }
-        r.v[it][0] = a;
-        r.v[it][1] = b;
+        // branch-free: out-of-range lanes read a clamped (valid) address; the zero is selected when the
+        // registers are written to LDS (stage_store_g), NOT here -- touching the loaded value now would
+        // put the s_waitcnt in front of the MFMAs this load is meant to hide behind
+        r.ok[it] = row < ROWS && grow < rows_total && k < K;
+        const int64_t crow = grow < rows_total ? grow : rows_total - 1;
+        const f32x4 *g = reinterpret_cast<const f32x4 *>(src + crow * (int64_t)K + (k < K ? k : 0));
+        r.v[it][0] = g[0];
+        r.v[it][1] = g[1];
     }
 }
 
@@ -282,7 +291,8 @@ __device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r
         const int p = t + it * THREADS;
         const int row = p >> 2, kg = p & 3;
         if (row < ROWS) {
-            const f32x4 a = r.v[it][0], b = r.v[it][1];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 a = r.ok[it] ? r.v[it][0] : z, b = r.ok[it] ? r.v[it][1] : z;
             f32x4 ev = {a[0], a[2], b[0], b[2]};
             f32x4 od = {a[1], a[3], b[1], b[3]};
             f32x4 *d = reinterpret_cast<f32x4 *>(lds + row * LDK + kg * 8);
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                         wf[g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + g * 8);
                     }
                 }
-                if (tune & 8) {
+                if (tune & (8 | 128)) {
                 } else if (half == 0) {
                     stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A0[u+1]
                     stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 1) * BK, gt);      // lower W[u+1]
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
             } else {
                 // ---- staging role: registers loaded during this group's last compute phase -> LDS
                 if (tune & 32) __builtin_amdgcn_s_setprio(0);
-                if (tune & 8) {
+                if (tune & (8 | 64)) {
                 } else if (half == 0) {
                     // group 1 in phase 2u: A1[u] (needed next phase) and the upper half of W[u+1]
                     stage_store_g<GM, 256>(ra, my_a, gt);
@@ -432,7 +442,7 @@ static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *
     const int bn_blocks = (out_dim + 127) / 128;
     const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
-    TraceScope trace(K_LINEAR_128x128, stream);
+    TraceScope trace(K_LINEAR_PP, stream);
     hipLaunchKernelGGL(linear_fwd_pp_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n, out_dim,
                        in_dim, relu, bn_blocks, (int)bm_blocks, tune);
     return check_launch("linear_fwd_pp_kernel");
@@ -446,7 +456,9 @@ static int launch_linear(const float *x, int64_t n, int in_dim, const float *W, 
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     const int64_t bm_blocks = (n + BM - 1) / BM;
     const int bn_blocks = (out_dim + BN - 1) / BN;
-    static const int tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return e ? atoi(e) : 0; }();
+    // bit 0 = XCD-aware tile order (default on: same speed, 2.3x less fabric traffic by FETCH_SIZE);
+    // the other bits are timing-only experiments and must stay 0 in production
+    static const int tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & LCREC_TUNE_MASK; }();
     const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
@@ -468,9 +480,17 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     if (((uintptr_t)x | (uintptr_t)W) & 15)
         return fail(LCREC_EINVAL, "linear_forward: x and W must be 16-byte aligned");
     if (n == 0) return LCREC_OK;
-    static const int pp = [] { const char *e = getenv("LCREC_GEMM_PP"); return e ? atoi(e) : 0; }();
-    static const int pp_tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return e ? atoi(e) : 0; }();
-    if (out_dim > 64 && pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
+    // Wide layers: the ping-pong kernel (one 512-thread workgroup per CU) wins once there are enough
+    // 256 x 128 tiles to keep every CU busy for several rounds; small problems keep the 128 x 128 kernel
+    // (three workgroups per CU, finer tail).  LCREC_GEMM_PP=0/1 forces one or the other (tuning only).
+    static const int pp = [] { const char *e = getenv("LCREC_GEMM_PP"); return e ? atoi(e) : -1; }();
+    static const int pp_tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & LCREC_TUNE_MASK; }();
+    const int64_t pp_tiles = ((n + 255) / 256) * ((out_dim + 127) / 128);
+    static const int pp_min = [] { const char *e = getenv("LCREC_GEMM_PP_MIN_TILES"); return e ? atoi(e) : 512; }();
+    // measured on MI355X: with >= 256 row blocks the ping-pong kernel wins at every width (C3/C4 chunks);
+    // at Games size (66 row blocks) the finer-grained 128x128 kernel is 5-10 % faster
+    const bool use_pp = out_dim > 64 && (pp == 1 || (pp == -1 && pp_tiles >= pp_min && n >= 256 * 256));
+    if (use_pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
     if (out_dim > 64) return launch_linear<2, 2, 2, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
     if (out_dim > 32) return launch_linear<4, 1, 1, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
     return launch_linear<4, 1, 1, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
