@@ -207,6 +207,7 @@ def main():
     # ping-pong kernel when the launch has >= 512 tiles and >= 65536 rows, else to the 128x128 kernel.
     macs_all = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1)) + sum(E_DIM * k for k in ks)
     flops = {"linear_fwd_pp_256x128": 0.0, "linear_fwd_128x128": 0.0}
+    alg_bytes = {"linear_fwd_pp_256x128": 0.0, "linear_fwd_128x128": 0.0}
     for lo in range(0, n, 131072):
         rows = min(131072, n - lo)
         for l in range(len(dims) - 1):
@@ -215,7 +216,10 @@ def main():
                 continue
             tiles = -(-rows // 256) * -(-out // 128)
             pp = tiles >= 512 and rows >= 65536 and os.environ.get("LCREC_GEMM_PP", "-1") != "0"
-            flops["linear_fwd_pp_256x128" if pp else "linear_fwd_128x128"] += 2.0 * rows * dims[l] * out * args.steps
+            kname = "linear_fwd_pp_256x128" if pp else "linear_fwd_128x128"
+            flops[kname] += 2.0 * rows * dims[l] * out * args.steps
+            # read the activations and the weights once, write the outputs once
+            alg_bytes[kname] += 4.0 * (rows * dims[l] + out * dims[l] + rows * out) * args.steps
     dom = max(flops, key=lambda k: flops[k])
     launches, total_ms = trace.get(dom, (0, 0.0))
     flops_dom_total = flops[dom]
@@ -230,6 +234,7 @@ def main():
         "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
         "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
         "flops_per_launch": (flops_dom_total / launches) if launches else None,
+        "algorithmic_bytes_per_launch": (alg_bytes[dom] / launches) if launches else None,
         "kernel_ms": {k: round(v[1], 3) for k, v in trace.items()},
     }
 
