@@ -114,6 +114,7 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
                                   float *latent_out, float *xq_out, double *sse_out, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
+    if (n == 0 && dims && K) return LCREC_OK;              // empty batch
     if (!x || !dims || !W || !b || !codebooks || !K || !idx_out)
         return fail(LCREC_EINVAL, "encode_assign: NULL pointer");
     if (n_layers < 1 || n_layers > LCREC_MAX_LAYERS)

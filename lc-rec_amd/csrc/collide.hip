@@ -140,7 +140,7 @@ size_t collision_workspace(int64_t n, int L)
 int collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t *members_out, int64_t *offsets_out,
                      int64_t *counters_out, void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    if (!idx || !K || !counters_out) return fail(LCREC_EINVAL, "collision_groups: NULL pointer");
+    if ((n > 0 && !idx) || !K || !counters_out) return fail(LCREC_EINVAL, "collision_groups: NULL pointer");
     if (n < 0 || L < 1 || L > LCREC_MAX_LEVELS) return fail(LCREC_EINVAL, "collision_groups: bad n or L");
     if ((members_out == nullptr) != (offsets_out == nullptr))
         return fail(LCREC_EINVAL, "collision_groups: members_out and offsets_out go together");

@@ -471,6 +471,7 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
                    const float *bn_scale, const float *bn_shift, int relu, int out_dim, float *y,
                    hipStream_t stream)
 {
+    if (n == 0) return LCREC_OK;                       // empty batch: nothing to read or write
     if (!x || !W || !y) return fail(LCREC_EINVAL, "linear_forward: NULL pointer");
     if (n < 0 || in_dim <= 0 || out_dim <= 0) return fail(LCREC_EINVAL, "linear_forward: bad shape");
     if ((bn_scale == nullptr) != (bn_shift == nullptr))

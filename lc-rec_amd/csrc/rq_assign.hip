@@ -359,6 +359,7 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
               int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
               void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
+    if (n == 0 && K && L >= 1 && L <= LCREC_MAX_LEVELS) return LCREC_OK;   // empty batch
     if (!z || !codebooks || !K || !idx_out) return fail(LCREC_EINVAL, "rq_assign: NULL pointer");
     if (n < 0 || L < 1 || L > LCREC_MAX_LEVELS) return fail(LCREC_EINVAL, "rq_assign: bad n=%lld or L=%d", (long long)n, L);
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e_dim=%d (supported: 16, 32, 64)", e);

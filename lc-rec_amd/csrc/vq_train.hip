@@ -598,6 +598,7 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
                     int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
                     hipStream_t stream)
 {
+    if (n == 0 || G == 0) return LCREC_OK;
     if (!r || !cb || !offs || !idx_out) return fail(LCREC_EINVAL, "sinkhorn_assign: NULL pointer");
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "sinkhorn_assign: e_dim=%d (supported: 16, 32, 64)", e);
     if (G < 0 || K < 1 || iters < 1 || !(eps > 0)) return fail(LCREC_EINVAL, "sinkhorn_assign: bad G/K/iters/eps");
@@ -649,6 +650,7 @@ int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, con
                 float *xq, int xq_accumulate, float *r_out, double *sse_out, void *workspace, size_t workspace_bytes,
                 hipStream_t stream)
 {
+    if (n == 0) return LCREC_OK;
     if (!r_in || !cb || !idx) return fail(LCREC_EINVAL, "rq_apply_level: NULL pointer");
     if (e % 4 || e <= 0 || K < 1 || n < 0) return fail(LCREC_EINVAL, "rq_apply_level: bad shape");
     if (n == 0) return LCREC_OK;
@@ -670,7 +672,7 @@ int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, con
 int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
                float *sum, hipStream_t stream)
 {
-    if (!idx || !resid || !count || !sum) return fail(LCREC_EINVAL, "code_stats: NULL pointer");
+    if ((n > 0 && (!idx || !resid)) || !count || !sum) return fail(LCREC_EINVAL, "code_stats: NULL pointer");
     if (n < 0 || K < 1) return fail(LCREC_EINVAL, "code_stats: bad shape");
     TraceScope trace(K_CODE_STATS, stream);
     if (e == 16) hipLaunchKernelGGL(code_stats_kernel<16>, dim3((K + 15) / 16), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);

@@ -1,0 +1,118 @@
+"""Edge cases on the MI355X: empty and single-row inputs, maximum and unsupported sizes, overflow,
+subnormals, degenerate codebooks -- always against the CPU oracle or an explicit expectation."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_empty_batches_are_a_no_op(hip):
+    ops = hip.ops
+    w = torch.randn(64, 32, device=DEV)
+    y = ops.linear_forward(torch.empty((0, 32), device=DEV), w, torch.zeros(64, device=DEV), relu=True)
+    assert tuple(y.shape) == (0, 64)
+    flat, ks = ops.flatten_codebooks([torch.randn(256, 32, device=DEV)] * 2)
+    idx, xq, sse, resid = ops.rq_assign(torch.empty((0, 32), device=DEV), flat, ks, want_xq=True, want_sse=True,
+                                        want_resid=True)
+    assert tuple(idx.shape) == (0, 2) and tuple(xq.shape) == (0, 32) and tuple(resid.shape) == (3, 0, 32)
+    assert sse.tolist() == [0.0, 0.0]
+    idx, _, _, _ = ops.encode_assign(torch.empty((0, 32), device=DEV), [w, torch.randn(32, 64, device=DEV)],
+                                     [torch.zeros(64, device=DEV), torch.zeros(32, device=DEV)], flat, ks)
+    assert tuple(idx.shape) == (0, 2)
+    got = ops.collision_groups(torch.empty((0, 4), dtype=torch.int64, device=DEV), [256] * 4)
+    assert got["unique"] == 0 and got["groups"] == [] and got["collision_rate"] == 0.0
+    cnt, tot = ops.code_stats(torch.empty(0, dtype=torch.int64, device=DEV), torch.empty((0, 32), device=DEV), 256)
+    assert float(cnt.sum()) == 0.0 and float(tot.abs().sum()) == 0.0
+
+
+def test_single_rows_and_maximum_depth(hip, oracle):
+    rs = np.random.RandomState(1)
+    for n, e, Ks in ((1, 64, [512]), (3, 16, [32] * 16), (65, 32, [1024, 32, 1, 7])):
+        z = rs.standard_normal((n, e)).astype(np.float32)
+        cbs = [rs.standard_normal((K, e)).astype(np.float32) for K in Ks]
+        want = oracle.rq_assign(z, cbs)
+        flat, ks = hip.ops.flatten_codebooks([t(c) for c in cbs])
+        idx, xq, _, _ = hip.ops.rq_assign(t(z), flat, ks, want_xq=True)
+        assert np.array_equal(idx.cpu().numpy(), want["idx"]) and np.array_equal(xq.cpu().numpy(), want["xq"])
+
+
+def test_unsupported_shapes_fail_loudly(hip):
+    ops = hip.ops
+    z = torch.randn(8, 32, device=DEV)
+    with pytest.raises(hip.LcrecError, match="does not fit"):
+        flat, ks = ops.flatten_codebooks([torch.randn(4096, 32, device=DEV)])
+        ops.rq_assign(z, flat, ks)
+    with pytest.raises(hip.LcrecError, match="e_dim=24"):
+        flat, ks = ops.flatten_codebooks([torch.randn(64, 24, device=DEV)])
+        ops.rq_assign(torch.randn(8, 24, device=DEV), flat, ks)
+    with pytest.raises(hip.LcrecError, match="multiple of 8"):
+        ops.linear_forward(torch.randn(4, 12, device=DEV), torch.randn(16, 12, device=DEV))
+    with pytest.raises(hip.LcrecError):
+        ops.linear_forward(torch.randn(4, 16, device=DEV, dtype=torch.float64), torch.randn(16, 16, device=DEV))
+    with pytest.raises(hip.LcrecError, match="128"):
+        ops.collision_groups(torch.zeros((4, 16), dtype=torch.int64, device=DEV), [1024] * 16)   # 160-bit tuples
+
+
+def test_overflow_and_subnormal_inputs_match_oracle(hip, oracle):
+    rs = np.random.RandomState(2)
+    e, K = 32, 256
+    cb = rs.standard_normal((K, e)).astype(np.float32)
+    z = rs.standard_normal((256, e)).astype(np.float32)
+    z[0] *= 1e30            # ||z||^2 overflows: every distance is +inf or nan-free inf-inf? -> oracle decides
+    z[1] = 1e-41            # subnormal latents survive both the CPU and the MFMA chain
+    z[2] = 0.0
+    cb[7] = 1e-42
+    want = oracle.rq_assign(z, [cb])
+    flat, ks = hip.ops.flatten_codebooks([t(cb)])
+    idx, xq, _, _ = hip.ops.rq_assign(t(z), flat, ks, want_xq=True)
+    rows = np.array([i for i in range(256) if np.isfinite(want["xq"][i]).all()])
+    assert np.array_equal(idx.cpu().numpy()[rows], want["idx"][rows])
+    assert np.array_equal(xq.cpu().numpy()[rows], want["xq"][rows])
+    assert 1 in rows and 2 in rows
+    # Linear with subnormal weights / huge activations
+    x = rs.standard_normal((130, 64)).astype(np.float32)
+    x[0] *= 1e-38
+    W = (rs.standard_normal((128, 64)) * 1e-3).astype(np.float32)
+    W[3] = 1e-43
+    b = np.zeros(128, np.float32)
+    got = hip.ops.linear_forward(t(x), t(W), t(b), relu=False).cpu().numpy()
+    assert np.array_equal(got, oracle.linear(x, W, b))
+
+
+def test_degenerate_codebooks(hip, oracle):
+    rs = np.random.RandomState(3)
+    z = rs.standard_normal((500, 32)).astype(np.float32)
+    same = np.tile(rs.standard_normal((1, 32)).astype(np.float32), (256, 1))      # all codes identical -> index 0
+    zero = np.zeros((256, 32), np.float32)
+    want = oracle.rq_assign(z, [same, zero])
+    flat, ks = hip.ops.flatten_codebooks([t(same), t(zero)])
+    idx, _, _, _ = hip.ops.rq_assign(t(z), flat, ks)
+    assert np.array_equal(idx.cpu().numpy(), want["idx"]) and int(idx.max()) == 0
+
+
+def test_sinkhorn_ragged_groups_with_empty_and_singleton(hip):
+    rs = np.random.RandomState(4)
+    sizes = [0, 1, 5, 0, 2, 1]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    n = offs[-1]
+    z = rs.standard_normal((n, 32)).astype(np.float32)
+    cb = rs.standard_normal((64, 32)).astype(np.float32)
+    out = hip.ops.sinkhorn_assign(t(z), t(cb), 0.003, 50, group_offsets=offs).cpu().numpy()
+    assert out.shape == (n,) and (out >= 0).all() and (out < 64).all()
+    # every non-empty group equals the CPU restatement run on that group alone; a 1 x K problem is
+    # degenerate (column normalisation makes all entries equal) and yields index 0, as torch's argmax does
+    from oracle import cpu_oracle, torch_ref
+    for g in range(len(sizes)):
+        lo, hi = offs[g], offs[g + 1]
+        if hi == lo:
+            continue
+        d = torch.from_numpy(cpu_oracle.distances(z[lo:hi], cb))
+        Q = torch_ref.sinkhorn(torch_ref.centre_distances(d).double(), 0.003, 50)
+        assert np.array_equal(out[lo:hi], torch.argmax(Q, -1).numpy()), g
+    assert out[0] == 0

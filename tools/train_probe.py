@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Secondary metric: RQ-VAE training-step throughput on one MI355X (reference index/trainer.py:111-120;
+the reference's CPU path does ~7-12 k items/s at batch 2048).
+
+    python tools/train_probe.py [--in_dim 768] [--batch 2048] [--steps 30] [--bn] [--ema]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lcrec_amd  # noqa: E402
+from lcrec_amd import ops  # noqa: E402
+from lcrec_amd.trainer import linear_schedule_with_warmup  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--in_dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--bn", action="store_true")
+    ap.add_argument("--ema", action="store_true")
+    ap.add_argument("--no_sk", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2024)
+    model = lcrec_amd.RQVAE(in_dim=a.in_dim, num_emb_list=[256] * 4, e_dim=32, layers=[2048, 1024, 512, 256, 128, 64],
+                            bn=a.bn, kmeans_init=False, sk_epsilons=[0.0, 0.0, 0.0, 0.0 if a.no_sk else 0.003],
+                            sk_iters=50, ema_decay=0.99 if a.ema else None).to(dev)
+    x = torch.randn((a.batch, a.in_dim), device=dev)
+    with torch.no_grad():   # data-scale codebooks
+        z = model.encoder(x)
+        for q in model.rq.vq_layers:
+            q.embedding.weight.copy_(z[torch.randperm(a.batch, device=dev)[:256]] * 0.5)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    sched = linear_schedule_with_warmup(opt, 10, 10000)
+
+    def step():
+        opt.zero_grad()
+        out, rq_loss, _ = model(x)
+        loss, _ = model.compute_loss(out, rq_loss, xs=x)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        sched.step()
+        return loss
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    ops.trace_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tr = ops.trace_collect()
+    ops.trace_enable(False)
+    print(f"in_dim {a.in_dim} batch {a.batch} bn {a.bn} ema {a.ema}: {dt / a.steps * 1e3:.3f} ms/step, "
+          f"{a.batch * a.steps / dt:,.0f} items/s, loss {loss.item():.4f}")
+    lib_ms = sum(v[1] for v in tr.values()) / a.steps
+    print(f"  lcrec kernels: {lib_ms:.3f} ms/step ->", {k: (v[0] // a.steps, round(v[1] / a.steps, 3)) for k, v in tr.items()})
+
+
+if __name__ == "__main__":
+    main()
