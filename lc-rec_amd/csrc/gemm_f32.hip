@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (g == 1) {
+                    if (g == 1) {   // second half's fragments: issued under the first half's MFMAs
 #pragma unroll
                         for (int gg = 2; gg < 4; ++gg) {
 #pragma unroll
@@ -461,7 +461,7 @@ static int launch_linear(const float *x, int64_t n, int in_dim, const float *W, 
     static const int tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & LCREC_TUNE_MASK; }();
     const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
-    TraceScope trace(BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
+    TraceScope trace(BM == 64 ? K_LINEAR_64x64 : BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
     hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN>), dim3((unsigned)grid), dim3(256), 0,
                        stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
     return check_launch("linear_fwd_kernel");
@@ -492,7 +492,13 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     // at Games size (66 row blocks) the finer-grained 128x128 kernel is 5-10 % faster
     const bool use_pp = out_dim > 64 && (pp == 1 || (pp == -1 && pp_tiles >= pp_min && n >= 256 * 256));
     if (use_pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
-    if (out_dim > 64) return launch_linear<2, 2, 2, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
+    if (out_dim > 64) {
+        // batch-sized problems (a training step has 1-2 k rows): 128 x 128 tiles would leave most CUs idle,
+        // so launches with fewer than two tiles per CU use 64 x 64 tiles (4x the workgroups)
+        const int64_t tiles128 = ((n + 127) / 128) * ((out_dim + 127) / 128);
+        if (tiles128 < 512) return launch_linear<2, 2, 1, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
+        return launch_linear<2, 2, 2, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
+    }
     if (out_dim > 32) return launch_linear<4, 1, 1, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
     return launch_linear<4, 1, 1, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
 }

@@ -10,6 +10,8 @@
 //   autograd of vq.py:90-92: dL/dC[k] ~ n_k*C[k] - S_k
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <vector>
 
 namespace lcrec {
@@ -545,6 +547,204 @@ size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G)
     return align_up((size_t)2 * G * sizeof(int64_t), 256) + (biggest ? sk_big_bytes(biggest, K) : 0);
 }
 
+// ------------------------------------------------------------------------------------------
+// Sinkhorn, training batch, ONE launch: every workgroup keeps its rows of Q in REGISTERS for the
+// whole solve (a wave owns RW rows, a lane CPL = K/64 columns of each: 32 VGPRs of fp64), row sums
+// are wave reductions, and only the per-workgroup column partials ([nblk][K] doubles) cross
+// workgroups -- through global memory behind a grid barrier, once per iteration.  Same divisions in
+// the same order as the multi-launch path, so the same bits.
+//
+// Grid barrier (guide: Guideline 16, counter form): monotonic agent-scope counter zeroed by a memset
+// node before the launch; lane 0 of each workgroup release-fences, adds 1, polls relaxed with
+// s_sleep until all workgroups of this phase have arrived, acquire-fences, then the workgroup's
+// barrier releases the other waves.  Every workgroup must be resident: the launcher only takes this
+// path for <= SKP_MAX_BLOCKS workgroups (one per CU, half the chip) and the spin is bounded -- on
+// timeout the kernel sets *flag and finishes (result invalid, reported by the host), it never hangs.
+// ------------------------------------------------------------------------------------------
+constexpr int SKP_THREADS = 512;
+constexpr int SKP_WAVES = SKP_THREADS / 64;
+constexpr int SKP_MAX_BLOCKS = 128;
+constexpr unsigned SKP_SPIN_LIMIT = 20u * 1000u * 1000u;     // ~ seconds of polling with s_sleep
+
+struct SkPersist {
+    const float *d;        // [B][K] fp32 distances
+    double *col_part;      // [2][nblk][K]
+    double *tot_part;      // [nblk]
+    const unsigned *minmax;
+    unsigned *counter;     // grid-barrier arrivals (zeroed before launch)
+    unsigned *flag;        // set to 1 on barrier timeout
+    int64_t B;
+    int K, nblk, iters;
+    double eps;
+    int64_t *idx_out;
+    int64_t idx_stride;
+};
+
+__device__ __forceinline__ void skp_grid_barrier(unsigned *counter, unsigned target, unsigned *flag)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SKP_SPIN_LIMIT) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+template <int CPL, int RW>
+__global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
+{
+    constexpr int ROWS = RW * SKP_WAVES;             // rows per workgroup
+    extern __shared__ __attribute__((aligned(16))) double skp_sm[];
+    double *colsum = skp_sm;                          // [K]
+    double *colacc = skp_sm + p.K;                    // [SKP_WAVES][K]
+    __shared__ double wsum[SKP_WAVES];
+    __shared__ double total_sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = p.K;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS + wave * RW;
+    const double Bd = (double)p.B, Kd = (double)K;
+    unsigned phase = 0;
+
+    const float hi = ord2f(p.minmax[1]), lo = ord2f(p.minmax[0]);
+    const float middle = (hi + lo) / 2.0f;
+    const float amplitude = (hi - middle) + 1e-5f;
+
+    double q[RW][CPL];
+    double part = 0.0;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            q[r][c] = 0.0;
+            if (row0 + r < p.B && j < K) {
+                const float cen = (p.d[(row0 + r) * K + j] - middle) / amplitude;
+                q[r][c] = exp(-(double)cen / p.eps);
+                part += q[r][c];
+            }
+        }
+    }
+    part = wave_sum(part);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < SKP_WAVES; ++w) s += wsum[w];
+        p.tot_part[blockIdx.x] = s;
+    }
+    skp_grid_barrier(p.counter, (++phase) * (unsigned)p.nblk, p.flag);
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < p.nblk; ++b) s += p.tot_part[b];
+        total_sh = s;
+    }
+    __syncthreads();
+    const double total = total_sh;
+
+    for (int it = 0; it < p.iters; ++it) {
+        double acc[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            double rs = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c;
+                if (row0 + r < p.B && j < K) {
+                    double v = q[r][c];
+                    if (it == 0) v = v / total;
+                    else { v = v / colsum[j]; v = v / Kd; }
+                    q[r][c] = v;
+                    rs += v;
+                }
+            }
+            rs = wave_sum(rs);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c;
+                if (row0 + r < p.B && j < K) {
+                    double v = q[r][c] / rs;
+                    v = v / Bd;
+                    q[r][c] = v;
+                    acc[c] += v;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            if (j < K) colacc[wave * K + j] = acc[c];
+        }
+        __syncthreads();
+        double *out = p.col_part + ((size_t)(it & 1) * p.nblk + blockIdx.x) * K;
+        for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
+            double s = 0.0;
+            for (int w = 0; w < SKP_WAVES; ++w) s += colacc[w * K + j];
+            out[j] = s;
+        }
+        skp_grid_barrier(p.counter, (++phase) * (unsigned)p.nblk, p.flag);
+        // colsum[j] = sum over workgroups, in workgroup order (every workgroup computes the same bits).
+        // The loads are issued 16 at a time: a one-at-a-time loop is a chain of L2 round trips.
+        const double *cp = p.col_part + (size_t)(it & 1) * p.nblk * K;
+        for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
+            double s = 0.0;
+            int b = 0;
+            for (; b + 16 <= p.nblk; b += 16) {
+                double v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = __builtin_nontemporal_load(cp + (size_t)(b + t) * K + j);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) s += v[t];
+            }
+            for (; b < p.nblk; ++b) s += cp[(size_t)b * K + j];
+            colsum[j] = s;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        double best = -1.0;
+        int bj = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            if (row0 + r < p.B && j < K) {
+                double v = q[r][c] / colsum[j];
+                v = v / Kd;
+                v = v * Bd;
+                if (v > best) { best = v; bj = j; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double b2 = __shfl_xor(best, o, 64);
+            const int j2 = __shfl_xor(bj, o, 64);
+            if (b2 > best || (b2 == best && j2 < bj)) { best = b2; bj = j2; }
+        }
+        // a barrier timeout anywhere poisons the output (-1) so the caller fails loudly instead of training on garbage
+        if (lane == 0 && row0 + r < p.B) {
+            const unsigned bad = __hip_atomic_load(p.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.idx_out[(row0 + r) * p.idx_stride] = bad ? -1 : bj;
+        }
+    }
+}
+
+template <int CPL, int RW>
+static void launch_skp(const SkPersist &p, hipStream_t stream)
+{
+    const size_t lds = (size_t)(1 + SKP_WAVES) * p.K * sizeof(double);
+    hipLaunchKernelGGL((sk_persistent_kernel<CPL, RW>), dim3((unsigned)p.nblk), dim3(SKP_THREADS), lds, stream, p);
+}
+
 static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K, double eps, int iters,
                         int64_t *idx_out, int64_t idx_stride, char *ws, hipStream_t stream)
 {
@@ -561,12 +761,35 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     ws += align_up((size_t)nblk * sizeof(double), 256);
     unsigned *minmax = reinterpret_cast<unsigned *>(ws);
     p.d = d; p.minmax = minmax; p.B = B; p.K = K; p.nblk = (int)nblk; p.eps = eps;
-    const unsigned init[2] = {0xffffffffu, 0u};
-    hipError_t he = hipMemcpyAsync(minmax, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    // {ord(min) = 0xffffffff, ord(max) = 0, barrier counter = 0, timeout flag = 0}: two memset nodes, no host buffer
+    hipError_t he = hipMemsetAsync(minmax, 0, 32, stream);
+    if (he == hipSuccess) he = hipMemsetAsync(minmax, 0xff, sizeof(unsigned), stream);
     if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn: %s", hipGetErrorString(he));
     int rc = vq_distances(r, B, e, cb, K, d, minmax, stream);
     if (rc) return rc;
+    if (iters == 0) return fail(LCREC_EUNSUPPORTED, "sinkhorn: iters must be >= 1");
     TraceScope trace(K_SINKHORN, stream);
+
+    // one-launch register-resident path when every workgroup can be resident (see sk_persistent_kernel)
+    const int cpl = (K + 63) / 64;
+    const int rows_p = cpl <= 4 ? 32 : (cpl <= 8 ? 16 : 8);
+    const int64_t nblk_p = (B + rows_p - 1) / rows_p;
+    static const bool allow_persistent = [] { const char *e = getenv("LCREC_SINKHORN_PERSISTENT"); return !e || atoi(e) != 0; }();
+    if (allow_persistent && nblk_p <= SKP_MAX_BLOCKS && nblk_p <= nblk * 4) {
+        SkPersist q;
+        // the Q region ([B][K] doubles) is unused on this path and holds the exchange buffers:
+        // 2*nblk_p*K + nblk_p doubles <= B*K/4 + B/8
+        q.d = d; q.col_part = p.Q; q.tot_part = p.Q + (size_t)2 * nblk_p * K; q.minmax = minmax;
+        q.counter = minmax + 4; q.flag = minmax + 5;
+        q.B = B; q.K = K; q.nblk = (int)nblk_p; q.iters = iters; q.eps = eps;
+        q.idx_out = idx_out; q.idx_stride = idx_stride;
+        if (cpl <= 1) launch_skp<1, 4>(q, stream);
+        else if (cpl <= 2) launch_skp<2, 4>(q, stream);
+        else if (cpl <= 4) launch_skp<4, 4>(q, stream);
+        else if (cpl <= 8) launch_skp<8, 2>(q, stream);
+        else launch_skp<16, 1>(q, stream);
+        return check_launch("sk_persistent_kernel");
+    }
     hipLaunchKernelGGL(sk_init_kernel, dim3((unsigned)nblk), dim3(SK_THREADS), 0, stream, p);
     const size_t lds_iter = (size_t)(1 + SK_THREADS / 64) * K * sizeof(double);
     int src = 0;
@@ -669,12 +892,90 @@ int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, con
     return check_launch("apply_level_kernel");
 }
 
+// Batch-sized problems (n <= CSS_MAX_N, the training case): ONE workgroup does a stable counting sort
+// of the items by code entirely in LDS, then thread (code, dim) adds only ITS items, still in item
+// order -- same bits as the streaming kernel and as the CPU, ~n/K additions per thread instead of n.
+constexpr int CSS_MAX_N = 8192;
+constexpr int CSS_MAX_K = 1024;
+constexpr int CSS_THREADS = 256;
+
+template <int E>
+__global__ __launch_bounds__(CSS_THREADS) void code_stats_sorted_kernel(const int64_t *__restrict__ idx, int64_t idx_stride,
+                                                                       const float *__restrict__ resid, int n, int K,
+                                                                       float *__restrict__ count, float *__restrict__ sum)
+{
+    __shared__ int skey[CSS_MAX_N];
+    __shared__ int order[CSS_MAX_N];
+    __shared__ int start[CSS_MAX_K + 1];
+    __shared__ int cursor[CSS_MAX_K];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < K; k += CSS_THREADS) cursor[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += CSS_THREADS) {
+        int k = (int)idx[(int64_t)i * idx_stride];
+        k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+        skey[i] = k;
+        atomicAdd(&cursor[k], 1);            // integer histogram: the totals do not depend on arrival order
+    }
+    __syncthreads();
+    if (tid == 0) {                          // K <= 1024: a serial exclusive scan is ~1 us
+        int run = 0;
+        for (int k = 0; k < K; ++k) { start[k] = run; run += cursor[k]; }
+        start[K] = run;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += CSS_THREADS) {
+        if (blockIdx.x == 0) count[k] = (float)cursor[k];
+        cursor[k] = start[k];
+    }
+    __syncthreads();
+    // stable placement, one chunk of CSS_THREADS items at a time, chunks in item order
+    for (int c0 = 0; c0 < n; c0 += CSS_THREADS) {
+        const int i = c0 + tid;
+        int key = -1, rank = 0, base = 0;
+        if (i < n) {
+            key = skey[i];
+            for (int j = c0; j < i; ++j) rank += (skey[j] == key) ? 1 : 0;   // earlier items of this chunk, same code
+            base = cursor[key];
+        }
+        __syncthreads();
+        if (i < n) {
+            order[base + rank] = i;
+            atomicAdd(&cursor[key], 1);
+        }
+        __syncthreads();
+    }
+    // per-code sums in item order.  The walk is a chain of dependent loads (~n/K per thread), so the codes
+    // are spread over the grid: every workgroup repeats the (cheap) sort and sums CSS_THREADS/E codes.
+    const int k = blockIdx.x * (CSS_THREADS / E) + tid / E, d = tid % E;
+    if (k < K) {
+        float acc = 0.f;
+        int p = start[k];
+        const int end = start[k + 1];
+        for (; p + 16 <= end; p += 16) {      // 16 loads in flight, then the additions in item order
+            float v[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = resid[(int64_t)order[p + t] * E + d];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc = acc + v[t];
+        }
+        for (; p < end; ++p) acc = acc + resid[(int64_t)order[p] * E + d];
+        sum[(size_t)k * E + d] = acc;
+    }
+}
+
 int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
                float *sum, hipStream_t stream)
 {
     if ((n > 0 && (!idx || !resid)) || !count || !sum) return fail(LCREC_EINVAL, "code_stats: NULL pointer");
     if (n < 0 || K < 1) return fail(LCREC_EINVAL, "code_stats: bad shape");
     TraceScope trace(K_CODE_STATS, stream);
+    if (n > 0 && n <= CSS_MAX_N && K <= CSS_MAX_K && (e == 16 || e == 32 || e == 64)) {
+        if (e == 16) hipLaunchKernelGGL(code_stats_sorted_kernel<16>, dim3((unsigned)((K * e + CSS_THREADS - 1) / CSS_THREADS)), dim3(CSS_THREADS), 0, stream, idx, idx_stride, resid, (int)n, K, count, sum);
+        else if (e == 32) hipLaunchKernelGGL(code_stats_sorted_kernel<32>, dim3((unsigned)((K * e + CSS_THREADS - 1) / CSS_THREADS)), dim3(CSS_THREADS), 0, stream, idx, idx_stride, resid, (int)n, K, count, sum);
+        else hipLaunchKernelGGL(code_stats_sorted_kernel<64>, dim3((unsigned)((K * e + CSS_THREADS - 1) / CSS_THREADS)), dim3(CSS_THREADS), 0, stream, idx, idx_stride, resid, (int)n, K, count, sum);
+        return check_launch("code_stats_sorted_kernel");
+    }
     if (e == 16) hipLaunchKernelGGL(code_stats_kernel<16>, dim3((K + 15) / 16), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);
     else if (e == 32) hipLaunchKernelGGL(code_stats_kernel<32>, dim3((K + 7) / 8), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);
     else if (e == 64) hipLaunchKernelGGL(code_stats_kernel<64>, dim3((K + 3) / 4), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);

@@ -177,6 +177,12 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
         rc = lib.lcrec_sinkhorn_assign(_ptr(resid), n, e, _ptr(codebook), K, oarr, G, float(epsilon), int(iters),
                                        _ptr(out), stride, _ptr(ws), ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_sinkhorn_assign")
+    if any((b - a) * K > 16384 for a, b in zip(offs[:-1], offs[1:])):
+        # the one-launch solver for batch-sized problems poisons its output with -1 if its (bounded)
+        # grid barrier ever times out; turn that into an error here rather than training on garbage
+        if bool((out < 0).any()):
+            raise _lib.LcrecError("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "
+                                  "set LCREC_SINKHORN_PERSISTENT=0 to use the multi-launch solver")
     return out
 
 

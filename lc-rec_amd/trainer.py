@@ -116,8 +116,10 @@ class Trainer(object):
         params = self.model.parameters()
         name = self.learner.lower()
         lr, wd = self.lr, self.weight_decay
+        # same update rule as the reference's default (foreach) implementation, in one kernel per step
+        fused = {"fused": True} if torch.device(self.args.device).type == "cuda" else {}
         if name == "adam":
-            return optim.Adam(params, lr=lr, weight_decay=wd)
+            return optim.Adam(params, lr=lr, weight_decay=wd, **fused)
         if name == "sgd":
             return optim.SGD(params, lr=lr, weight_decay=wd)
         if name == "adagrad":
@@ -130,7 +132,7 @@ class Trainer(object):
         if name == "rmsprop":
             return optim.RMSprop(params, lr=lr, weight_decay=wd)
         if name == "adamw":
-            return optim.AdamW(params, lr=lr, weight_decay=wd)
+            return optim.AdamW(params, lr=lr, weight_decay=wd, **fused)
         self.logger.warning("Received unrecognized optimizer, set default Adam optimizer")
         return optim.Adam(params, lr=lr)
 

@@ -192,7 +192,7 @@ def test_sinkhorn_collision_groups(hip, K, e):
     assert nbad <= max(1, n // 500)
 
 
-@pytest.mark.parametrize("n,e,K", [(1000, 32, 256), (77, 16, 48), (5000, 64, 128)])
+@pytest.mark.parametrize("n,e,K", [(1000, 32, 256), (77, 16, 48), (5000, 64, 128), (8192, 32, 1024), (20000, 32, 256)])
 def test_apply_level_and_code_stats_bit_exact(hip, oracle, n, e, K):
     rs = _rs(n + e + K)
     z = rs.standard_normal((n, e)).astype(np.float32)

@@ -40,14 +40,16 @@ def test_eval_forward_matches_reference(hip, bn):
     np.testing.assert_allclose(recon.item(), float(g["eval_loss_recon"]), rtol=1e-5)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("bn", [0, 1])
-def test_training_steps_match_reference(hip, bn):
+def test_training_steps_match_reference(hip, bn, fused):
     """trainer.py:111-120 three times: forward (Sinkhorn on the last level), loss, backward,
     clip 1.0, AdamW, linear warm-up -- against the reference's recorded trajectory."""
     from lcrec_amd.trainer import linear_schedule_with_warmup
     g, model, x = _tiny(hip, bn)
     model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    # fused=True is what lcrec_amd.trainer.Trainer builds on a HIP device: same rule, one kernel
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=fused)
     sched = linear_schedule_with_warmup(opt, num_warmup_steps=2, num_training_steps=10)
     traj = g["trajectory"]
     for step in range(3):
