@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (first, so the HIP runtime torch ships is the one this library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblcrec_hip.so")
+LIB_PATH = os.environ.get("LCREC_LIB_PATH") or os.path.join(_HERE, "csrc", "liblcrec_hip.so")   # override: diagnostic builds
 
 _f32p = ctypes.c_void_p
 _vp = ctypes.c_void_p

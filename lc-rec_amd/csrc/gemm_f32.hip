@@ -13,14 +13,18 @@
 // so feeding it k = 2s (low half) and 2s+1 (high half) for s ascending, into one
 // accumulator, reproduces the chain exactly.  There is no split-K.
 //
-// Tiling: 256 threads = 4 waves.  Block tile BM x BN, K step 32.  Each wave
-// owns TM x TN MFMA tiles of 32x32.  Operand tiles go global -> registers ->
-// LDS (next tile's loads are issued before the current tile's MFMAs).  LDS
-// rows hold a 32-wide K slice with k de-interleaved inside each group of 8
-// ([k0 k2 k4 k6 | k1 k3 k5 k7]) so that one ds_read_b128 per lane yields the
-// lane's operand for four consecutive MFMAs; rows are padded to 36 floats,
-// which makes both the ds_write_b128 and the ds_read_b128 pattern
-// bank-conflict free (16 consecutive rows cover 16 distinct 4-bank slots).
+// Two kernels, one arithmetic (the dispatch is at the bottom of the file):
+//   linear_fwd_kernel<WM,WN,TM,TN>  256 threads = 4 waves, block tile (WM*TM*32) x (WN*TN*32): 128x128 for
+//                                   mid-sized launches, 64x64 for batch-sized ones, 128x64 / 128x32 for the
+//                                   narrow tail layers; several workgroups per CU hide each other's stalls;
+//   linear_fwd_pp_kernel            512 threads, 256x128 tile, for chunk-sized launches: the two waves of a
+//                                   SIMD alternate between "64 MFMAs" and "stage the next tile" (see there).
+// Common: K step 32.  Operand tiles go global -> registers -> LDS (the next tile's loads are issued
+// before the current tile's MFMAs).  LDS rows hold a 32-wide K slice with k de-interleaved inside
+// each group of 8 ([k0 k2 k4 k6 | k1 k3 k5 k7]) so that one ds_read_b128 per lane yields the lane's
+// operand for four consecutive MFMAs; rows are padded to 36 floats, which makes both the
+// ds_write_b128 and the ds_read_b128 pattern bank-conflict free (16 consecutive rows cover 16
+// distinct 4-bank slots; SQ_LDS_BANK_CONFLICT measures 0).
 #include "common.h"
 
 #include <stdlib.h>
@@ -33,6 +37,21 @@ namespace lcrec {
 #define LCREC_TUNE_MASK 0xff
 #else
 #define LCREC_TUNE_MASK 0x1
+#endif
+
+// In-kernel cycle stamps (diagnostic builds only: make STAMP=1, then lcrec_debug_gemm_stamps()).
+#ifdef LCREC_GEMM_STAMP
+__device__ unsigned long long g_stamps[8][64][4];
+#define LCREC_STAMP(slot)                                                                          \
+    do {                                                                                           \
+        if (blockIdx.x == 8 && lane == 0 && 2 * u + half < 64) {                                   \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            g_stamps[wave][2 * u + half][slot] = t_;                                               \
+        }                                                                                          \
+    } while (0)
+#else
+#define LCREC_STAMP(slot) do { } while (0)
 #endif
 
 constexpr int BK = 32;   // K slice per step
@@ -162,19 +181,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     }
     const int64_t m0 = bm * BM;
     const int n0 = bn * BN;
-    // Co-resident workgroups run the same program and tend to hit their barriers together; distinct
-    // wave priorities let one of them own the MFMA pipe while the others stage.
-    if (tune & 2) {
-        const int pr = (blockIdx.x >> 8) & 3;
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
-    if (tune & 4) {
-        const int ph = (blockIdx.x >> 8) % 3;
-        if (ph == 1) __builtin_amdgcn_s_sleep(20);
-        else if (ph == 2) __builtin_amdgcn_s_sleep(40);
-    }
+    // (Measured and dropped: static per-workgroup s_setprio levels cost 4 %, start-up staggering of
+    // co-resident workgroups changed nothing.)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -262,7 +270,7 @@ struct StageRegsG {
     bool ok[ITERS];
 };
 
-template <int ROWS, int THREADS>
+template <int ROWS, int THREADS, bool FULL = false>
 __device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const float *__restrict__ src, int64_t row0,
                                              int64_t rows_total, int K, int k0, int t)
 {
@@ -272,6 +280,15 @@ __device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const
         const int row = p >> 2, kg = p & 3;
         const int64_t grow = row0 + row;
         const int k = k0 + kg * 8;
+        if constexpr (FULL) {
+            // interior tile (host-checked: every row and the whole K slice are in range): plain loads, no
+            // guards -- every instruction of the staging role steals MFMA issue slots (see the kernel)
+            static_assert(ROWS * 4 % THREADS == 0, "exact cover");
+            const f32x4 *g = reinterpret_cast<const f32x4 *>(src + grow * (int64_t)K + k);
+            r.v[it][0] = g[0];
+            r.v[it][1] = g[1];
+            continue;
+        }
         // branch-free: out-of-range lanes read a clamped (valid) address; the zero is selected when the
         // registers are written to LDS (stage_store_g), NOT here -- touching the loaded value now would
         // put the s_waitcnt in front of the MFMAs this load is meant to hide behind
@@ -283,7 +300,7 @@ __device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const
     }
 }
 
-template <int ROWS, int THREADS>
+template <int ROWS, int THREADS, bool FULL = false>
 __device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r, float *lds, int t)
 {
 #pragma unroll
@@ -292,7 +309,7 @@ __device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r
         const int row = p >> 2, kg = p & 3;
         if (row < ROWS) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 a = r.ok[it] ? r.v[it][0] : z, b = r.ok[it] ? r.v[it][1] : z;
+            const f32x4 a = (FULL || r.ok[it]) ? r.v[it][0] : z, b = (FULL || r.ok[it]) ? r.v[it][1] : z;
             f32x4 ev = {a[0], a[2], b[0], b[2]};
             f32x4 od = {a[1], a[3], b[1], b[3]};
             f32x4 *d = reinterpret_cast<f32x4 *>(lds + row * LDK + kg * 8);
@@ -302,6 +319,7 @@ __device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r
     }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
@@ -311,7 +329,10 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
     __shared__ __attribute__((aligned(16))) float As[2][GM * LDK];
     __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // readfirstlane makes the wave index (hence the role branches and the s_setprio inside them, a scalar
+    // instruction that ignores EXEC) provably wave-uniform: real s_cbranch_scc branches, not exec masking
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
     const int gt = tid & 255;
 
@@ -345,13 +366,14 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
     float *my_a = As[grp];
 
     // ---- prologue: W[0] (both halves) and A0[0] into LDS; group 1 leaves (A1[0], upper W[1]) in registers
-    stage_load_g<64, 256>(rw, W, w_row0, N, K, 0, gt);
-    stage_store_g<64, 256>(rw, Ws[0] + grp * 64 * LDK, gt);
-    stage_load_g<GM, 256>(ra, A, m0, M, K, 0, gt);
+    stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, 0, gt);
+    stage_store_g<64, 256, FULL>(rw, Ws[0] + grp * 64 * LDK, gt);
+    stage_load_g<GM, 256, FULL>(ra, A, m0, M, K, 0, gt);
     if (grp == 0) {
-        stage_store_g<GM, 256>(ra, my_a, gt);
+        stage_store_g<GM, 256, FULL>(ra, my_a, gt);
     } else {
-        stage_load_g<64, 256>(rw, W, w_row0, N, K, BK, gt);      // upper W[1] (zeros if nk == 1)
+        // upper W[1]; the guard-free variant must not read past K (the generic one returns zeros there)
+        if (!FULL || nk > 1) stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, BK, gt);
     }
     __syncthreads();
 
@@ -367,6 +389,12 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                 // wave on this SIMD is still issuing the second half of ITS tile, which hides their
                 // latency), then the global prefetch of the next tiles; the phase barrier sits after the
                 // LAST LDS read, so this wave's remaining 32 MFMAs overlap the partner's next phase.
+                LCREC_STAMP(0);
+                // Issue arbitration on a SIMD is priority, then age: a wave with back-to-back MFMAs queued
+                // starves its partner completely (measured with in-kernel stamps).  So every NON-MFMA stretch
+                // (fragment reads + global prefetch here, the LDS writes of the staging role) runs at raised
+                // priority and slips into the partner's MFMA stream, whose pipe stays busy 64 cycles per issue.
+                if (!(tune & 32)) __builtin_amdgcn_s_setprio(2);
                 f32x4 af[4][2], wf[4][2];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
@@ -378,12 +406,17 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                 }
                 if (tune & (8 | 128)) {
                 } else if (half == 0) {
-                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A0[u+1]
-                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 1) * BK, gt);      // lower W[u+1]
+                    // (tiles past the last one are never consumed: the guard-free variant skips their loads
+                    // instead of reading beyond K; the generic variant loads zeros)
+                    if (!FULL || u + 1 < nk) {
+                        stage_load_g<GM, 256, FULL>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A0[u+1]
+                        stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, (u + 1) * BK, gt);      // lower W[u+1]
+                    }
                 } else {
-                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A1[u+1]
-                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 2) * BK, gt);      // upper W[u+2]
+                    if (!FULL || u + 1 < nk) stage_load_g<GM, 256, FULL>(ra, A, m0, M, K, (u + 1) * BK, gt);     // A1[u+1]
+                    if (!FULL || u + 2 < nk) stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, (u + 2) * BK, gt); // upper W[u+2]
                 }
+                if (!(tune & 32)) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (g == 1) {   // second half's fragments: issued under the first half's MFMAs
@@ -396,8 +429,11 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                             }
                         }
                     }
-                    if (g == 2 && !(tune & 16)) __syncthreads();
-                    if (g == 0 && (tune & 32)) __builtin_amdgcn_s_setprio(2);
+                    if (g == 2) {
+                        LCREC_STAMP(1);
+                        if (!(tune & 16)) __syncthreads();
+                        LCREC_STAMP(2);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -406,23 +442,29 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                             for (int j = 0; j < 2; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][q], wf[g][j][q], acc[i][j], 0, 0, 0);
                 }
+                LCREC_STAMP(3);
             } else {
                 // ---- staging role: registers loaded during this group's last compute phase -> LDS
-                if (tune & 32) __builtin_amdgcn_s_setprio(0);
+                LCREC_STAMP(0);
+                if (!(tune & 32)) __builtin_amdgcn_s_setprio(2);
                 if (tune & (8 | 64)) {
                 } else if (half == 0) {
                     // group 1 in phase 2u: A1[u] (needed next phase) and the upper half of W[u+1]
-                    stage_store_g<GM, 256>(ra, my_a, gt);
-                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1] + 64 * LDK, gt);
+                    stage_store_g<GM, 256, FULL>(ra, my_a, gt);
+                    stage_store_g<64, 256, FULL>(rw, Ws[(u + 1) & 1] + 64 * LDK, gt);
                 } else {
                     // group 0 in phase 2u+1: A0[u+1] and the lower half of W[u+1]
-                    stage_store_g<GM, 256>(ra, my_a, gt);
-                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1], gt);
+                    stage_store_g<GM, 256, FULL>(ra, my_a, gt);
+                    stage_store_g<64, 256, FULL>(rw, Ws[(u + 1) & 1], gt);
                 }
+                LCREC_STAMP(1);
                 if (!(tune & 16)) __syncthreads();
+                LCREC_STAMP(2);
+                // stay at raised priority: the next thing this wave does is the compute role's fragment reads
             }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
 
     // epilogue: each wave transposes through 32 rows of its OWN group's activation buffer (its last
     // LDS operand read is behind the final mid-phase barrier; the other group never touches it)
@@ -443,8 +485,14 @@ static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *
     const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(K_LINEAR_PP, stream);
-    hipLaunchKernelGGL(linear_fwd_pp_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n, out_dim,
-                       in_dim, relu, bn_blocks, (int)bm_blocks, tune);
+    // every tile interior (rows % 256 == 0, columns % 128 == 0, K % 32 == 0): the guard-free instantiation
+    const bool full = n % 256 == 0 && out_dim % 128 == 0 && in_dim % BK == 0;
+    if (full)
+        hipLaunchKernelGGL(linear_fwd_pp_kernel<true>, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
+                           out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
+    else
+        hipLaunchKernelGGL(linear_fwd_pp_kernel<false>, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
+                           out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
     return check_launch("linear_fwd_pp_kernel");
 }
 
@@ -491,7 +539,15 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     // measured on MI355X: with >= 256 row blocks the ping-pong kernel wins at every width (C3/C4 chunks);
     // at Games size (66 row blocks) the finer-grained 128x128 kernel is 5-10 % faster
     const bool use_pp = out_dim > 64 && (pp == 1 || (pp == -1 && pp_tiles >= pp_min && n >= 256 * 256));
-    if (use_pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
+    if (use_pp) {
+        // whole 256-row panels go to the ping-pong kernel (guard-free when the widths divide too); the
+        // remaining < 256 rows are a second, small launch of the generic kernel -- same bits either way
+        const int64_t n_full = (out_dim % 128 == 0 && in_dim % BK == 0) ? n / 256 * 256 : n;
+        int rc = n_full ? launch_linear_pp(x, n_full, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream) : 0;
+        if (rc || n_full == n) return rc;
+        return launch_linear<2, 2, 1, 1>(x + n_full * in_dim, n - n_full, in_dim, W, b, bn_scale, bn_shift, relu, out_dim,
+                                         y + n_full * (int64_t)out_dim, stream);
+    }
     if (out_dim > 64) {
         // batch-sized problems (a training step has 1-2 k rows): 128 x 128 tiles would leave most CUs idle,
         // so launches with fewer than two tiles per CU use 64 x 64 tiles (4x the workgroups)
@@ -504,3 +560,10 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
 }
 
 }  // namespace lcrec
+
+#ifdef LCREC_GEMM_STAMP
+extern "C" __attribute__((visibility("default"))) int lcrec_debug_gemm_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcrec::g_stamps), sizeof(unsigned long long) * 8 * 64 * 4);
+}
+#endif

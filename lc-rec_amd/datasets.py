@@ -34,10 +34,28 @@ class EmbDataset(data.Dataset):
             return self._device_copy
         n = len(self)
         out = torch.empty((n, self.dim), dtype=torch.float32, device=device)
-        for lo in range(0, n, chunk_rows):
-            hi = min(n, lo + chunk_rows)
-            block = torch.from_numpy(np.ascontiguousarray(self.embeddings[lo:hi], dtype=np.float32))
-            out[lo:hi].copy_(block, non_blocking=False)
+        if device.type != "cuda":
+            for lo in range(0, n, chunk_rows):
+                hi = min(n, lo + chunk_rows)
+                out[lo:hi].copy_(torch.from_numpy(np.ascontiguousarray(self.embeddings[lo:hi], dtype=np.float32)))
+            self._device_copy = out
+            return out
+        # two pinned staging buffers: the host-side cast of chunk i+1 overlaps the H2D copy of chunk i
+        rows = min(chunk_rows, max(n, 1))
+        stage = [torch.empty((rows, self.dim), dtype=torch.float32).pin_memory() for _ in range(2)]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        copier = torch.cuda.Stream(device)
+        for i, lo in enumerate(range(0, n, rows)):
+            hi = min(n, lo + rows)
+            buf = stage[i % 2]
+            if i >= 2:
+                done[i % 2].synchronize()            # the copy that last used this buffer has finished
+            np.copyto(buf[:hi - lo].numpy(), self.embeddings[lo:hi], casting="unsafe")
+            with torch.cuda.stream(copier):
+                out[lo:hi].copy_(buf[:hi - lo], non_blocking=True)
+                done[i % 2].record(copier)
+        copier.synchronize()
+        torch.cuda.current_stream(device).wait_stream(copier)
         self._device_copy = out
         return out
 
