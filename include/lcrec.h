@@ -170,6 +170,19 @@ int lcrec_collision_groups(const int64_t *idx, int64_t n, int L, const int *K, i
                            int64_t *group_offsets_out, int64_t *counters_out, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* Text of the `.index.json` entries for a run of items (host-side; no device work).  Replaces the
+ * per-item Python of index/generate_indices.py:83-92 (token strings "<a_{i}>", "<b_{j}>", ...) and the
+ * json.dump of :138-145, whose default separators (", " and ": ") every consumer relies on
+ * (data.py:38-89 json.load's the file).  For items first_item .. first_item+n-1 the output is
+ *     "<id>": ["<a_i>", "<b_j>", ...], "<id+1>": [...]
+ * -- entries joined by ", ", no enclosing braces, no trailing separator, no NUL -- so that
+ * "{" + chunk_0 + ", " + chunk_1 + ... + "}" is byte-for-byte json.dump's output for the whole dict.
+ *   idx   HOST [n][L] int64 (row-major), 1 <= L <= 26 (prefix letters a..z)
+ *   out   HOST buffer of capacity cap bytes; lcrec_index_json_bound(n, L) is always enough
+ * Returns the number of bytes written, or a negative LCREC_E* code (LCREC_EWORKSPACE: cap too small). */
+int64_t lcrec_index_json_bound(int64_t n, int L);
+int64_t lcrec_index_json_format(const int64_t *idx, int64_t n, int L, int64_t first_item, char *out, int64_t cap);
+
 /* Kernel tracing (diagnostic; the reference has no tracing on this path -- its only
  * timing is wall-clock per epoch, index/trainer.py:193-195).  While enabled, every
  * kernel this library launches is bracketed by a pair of hipEvents recorded on the

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "lcrec_collision_groups_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "lcrec_collision_groups": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _vp,
                                               _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_index_json_bound": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
+    "lcrec_index_json_format": (ctypes.c_int64, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int64]),
     "lcrec_trace_enable": (ctypes.c_int, [ctypes.c_int]),
     "lcrec_trace_collect": (ctypes.c_int, [_vp, ctypes.c_int]),
 }

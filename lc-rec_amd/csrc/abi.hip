@@ -216,6 +216,13 @@ LCREC_API int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook
     return ema_update(ema_count, ema_sum, codebook, count, sum, K, e, decay, alpha, keep, eps, (hipStream_t)stream);
 }
 
+LCREC_API int64_t lcrec_index_json_bound(int64_t n, int L) { return index_json_bound(n, L); }
+
+LCREC_API int64_t lcrec_index_json_format(const int64_t *idx, int64_t n, int L, int64_t first_item, char *out, int64_t cap)
+{
+    return index_json_format(idx, n, L, first_item, out, cap);
+}
+
 LCREC_API size_t lcrec_collision_groups_workspace(int64_t n, int L) { return collision_workspace(n, L); }
 
 LCREC_API int lcrec_collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t *members_out,

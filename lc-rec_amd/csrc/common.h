@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/lcrec.h"
 
@@ -69,5 +70,9 @@ int collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t
                      int64_t *counters_out, void *workspace, size_t workspace_bytes, hipStream_t stream);
 int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,
                float decay, float alpha, float keep, float eps, hipStream_t stream);
+
+// host-side text (index_json.hip)
+int64_t index_json_bound(int64_t n, int L);
+int64_t index_json_format(const int64_t *idx, int64_t n, int L, int64_t first_item, char *out, int64_t cap);
 
 }  // namespace lcrec

@@ -25,38 +25,41 @@ class EmbDataset(data.Dataset):
     def __len__(self):
         return len(self.embeddings)
 
-    def to_device(self, device, chunk_rows=1 << 18):
-        """The whole matrix as one fp32 tensor in HBM (Games: 16 859 x 4096 = 276 MB; a 288 GB
-        MI355X holds 17 M such rows).  Cast and copied in row chunks so a large or memory-mapped
-        file never needs a second full host copy."""
+    def to_device(self, device, chunk_rows=1 << 18, rows=None):
+        """The matrix (or the item range rows=(lo, hi), one rank's shard) as one fp32 tensor in HBM
+        (Games: 16 859 x 4096 = 276 MB; a 288 GB MI355X holds 17 M such rows).  Cast and copied in row
+        chunks so a large or memory-mapped file never needs a second full host copy."""
         device = torch.device(device)
-        if self._device_copy is not None and self._device_copy.device == device:
+        whole = rows is None
+        if whole and self._device_copy is not None and self._device_copy.device == device:
             return self._device_copy
-        n = len(self)
+        first, last = (0, len(self)) if whole else (int(rows[0]), int(rows[1]))
+        n = last - first
         out = torch.empty((n, self.dim), dtype=torch.float32, device=device)
         if device.type != "cuda":
             for lo in range(0, n, chunk_rows):
                 hi = min(n, lo + chunk_rows)
-                out[lo:hi].copy_(torch.from_numpy(np.ascontiguousarray(self.embeddings[lo:hi], dtype=np.float32)))
+                out[lo:hi].copy_(torch.from_numpy(np.ascontiguousarray(self.embeddings[first + lo:first + hi],
+                                                                       dtype=np.float32)))
+        else:
+            # two pinned staging buffers: the host-side cast of chunk i+1 overlaps the H2D copy of chunk i
+            step = min(chunk_rows, max(n, 1))
+            stage = [torch.empty((step, self.dim), dtype=torch.float32).pin_memory() for _ in range(2)]
+            done = [torch.cuda.Event(), torch.cuda.Event()]
+            copier = torch.cuda.Stream(device)
+            for i, lo in enumerate(range(0, n, step)):
+                hi = min(n, lo + step)
+                buf = stage[i % 2]
+                if i >= 2:
+                    done[i % 2].synchronize()            # the copy that last used this buffer has finished
+                np.copyto(buf[:hi - lo].numpy(), self.embeddings[first + lo:first + hi], casting="unsafe")
+                with torch.cuda.stream(copier):
+                    out[lo:hi].copy_(buf[:hi - lo], non_blocking=True)
+                    done[i % 2].record(copier)
+            copier.synchronize()
+            torch.cuda.current_stream(device).wait_stream(copier)
+        if whole:
             self._device_copy = out
-            return out
-        # two pinned staging buffers: the host-side cast of chunk i+1 overlaps the H2D copy of chunk i
-        rows = min(chunk_rows, max(n, 1))
-        stage = [torch.empty((rows, self.dim), dtype=torch.float32).pin_memory() for _ in range(2)]
-        done = [torch.cuda.Event(), torch.cuda.Event()]
-        copier = torch.cuda.Stream(device)
-        for i, lo in enumerate(range(0, n, rows)):
-            hi = min(n, lo + rows)
-            buf = stage[i % 2]
-            if i >= 2:
-                done[i % 2].synchronize()            # the copy that last used this buffer has finished
-            np.copyto(buf[:hi - lo].numpy(), self.embeddings[lo:hi], casting="unsafe")
-            with torch.cuda.stream(copier):
-                out[lo:hi].copy_(buf[:hi - lo], non_blocking=True)
-                done[i % 2].record(copier)
-        copier.synchronize()
-        torch.cuda.current_stream(device).wait_stream(copier)
-        self._device_copy = out
         return out
 
 

@@ -27,6 +27,7 @@ import json
 import logging
 import os
 
+import numpy as np
 import torch
 
 from . import ops
@@ -120,19 +121,16 @@ def resolve_collisions(model, idx, resid_last, ks, max_rounds=MAX_ROUNDS, on_rou
     L = len(levels)
     history = []
     for _ in range(max_rounds):
-        found = ops.collision_groups(idx, ks, want_groups=True)
-        groups = found["groups"]
-        if not groups:
+        found = ops.collision_groups(idx, ks, want_groups="device")
+        if found["n_groups"] == 0:
             break
-        history.append(len(groups))
+        history.append(found["n_groups"])
         if on_round is not None:
-            on_round(len(history) - 1, groups)
-        members = torch.tensor([i for g in groups for i in g], dtype=torch.int64, device=idx.device)
-        offsets = [0]
-        for g in groups:
-            offsets.append(offsets[-1] + len(g))
+            on_round(len(history) - 1, found["n_groups"])
+        members = found["members"]
         rows = resid_last.index_select(0, members)
-        new_last = ops.sinkhorn_assign(rows, cb_last, last.sk_epsilon, last.sk_iters, group_offsets=offsets)
+        new_last = ops.sinkhorn_assign(rows, cb_last, last.sk_epsilon, last.sk_iters,
+                                       group_offsets=found["offsets"].cpu().numpy())
         idx[members, L - 1] = new_last
     return idx, history
 
@@ -145,65 +143,100 @@ def tokens_for(idx_rows):
     return [[PREFIX[l].format(int(v)) for l, v in enumerate(row)] for row in idx_rows]
 
 
-def dump_index_json(idx_rows, path):
-    """Exactly the bytes of `json.dump({item: tokens}, fp)` (:138-145) without building the dict of
-    N Python lists first: keys are item ids in order, separators are json's defaults."""
-    L = len(idx_rows[0]) if idx_rows else 0
-    fmt = '"{0}": [' + ", ".join('"' + PREFIX[l].replace("{}", "{%d}" % (l + 1)) + '"' for l in range(L)) + "]"
-    with open(path, "w") as fp:
-        fp.write("{")
-        step = 1 << 16
-        for lo in range(0, len(idx_rows), step):
-            chunk = idx_rows[lo:lo + step]
-            text = ", ".join(fmt.format(lo + i, *row) for i, row in enumerate(chunk))
+def dump_index_json(idx_rows, path, chunk_items=1 << 20):
+    """Exactly the bytes of `json.dump({str(item): tokens}, fp)` (:138-145) for an int64 [N, L] index
+    matrix (tensor, ndarray or nested list): keys are item ids in order, separators are json's defaults.
+    The text is produced by the library (lcrec_index_json_format), a chunk of items at a time."""
+    if isinstance(idx_rows, torch.Tensor):
+        idx_rows = idx_rows.detach().cpu().numpy()
+    rows = np.asarray(idx_rows, dtype=np.int64)
+    if rows.ndim != 2:
+        rows = rows.reshape(len(rows), -1)
+    if rows.shape[1] > len(PREFIX):
+        raise ValueError(f"{rows.shape[1]} levels: no token prefix beyond <z_..>")
+    with open(path, "wb") as fp:
+        fp.write(b"{")
+        for lo in range(0, rows.shape[0], chunk_items):
             if lo:
-                fp.write(", ")
-            fp.write(text)
-        fp.write("}")
+                fp.write(b", ")
+            fp.write(ops.index_json_text(rows[lo:lo + chunk_items], first_item=lo))
+        fp.write(b"}")
 
 
-def _warn_if_reference_would_truncate(first_pass_rows, final_rows):
-    def digits(rows):
-        return max((len(str(int(v))) for row in rows for v in row), default=0), \
-            max((sum(len(str(int(v))) for v in row) for row in rows), default=0)
-    tok0, sum0 = digits(first_pass_rows)
-    tok1, sum1 = digits(final_rows)
+def _digits(t):
+    """decimal digit count of non-negative int64 values, elementwise"""
+    d = torch.ones_like(t)
+    p = 10
+    for _ in range(18):
+        d += (t >= p).to(t.dtype)
+        p *= 10
+    return d
+
+
+def _warn_if_reference_would_truncate(first_pass, final):
+    def widths(t):
+        if t.numel() == 0:
+            return 0, 0
+        d = _digits(t.clamp_min(0))
+        return int(d.max()), int(d.sum(1).max())
+    tok0, sum0 = widths(first_pass)
+    tok1, sum1 = widths(final)
     if tok1 > tok0 or sum1 > sum0:
         log.warning("a re-assigned index is wider than anything in pass 1: the reference's fixed-width numpy "
                     "string arrays (generate_indices.py:98-99) would truncate it; this output keeps it intact")
 
 
-def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True):
-    """Whole flow of generate_indices.py:51-145.  Returns a dict of the statistics it prints."""
+def sharded_assign(ctx, data, assign_fn, device):
+    """Pass 1 over this rank's contiguous item range, then ONE gather of (index rows, last-level
+    residuals) in rank order: afterwards every rank holds what a single process would have computed
+    (items are independent in pass 1, so the shard boundaries do not show in the result).
+    `assign_fn(x) -> (idx [n, L], resid_last [n, e], ks)`; `data` is an EmbDataset or a tensor."""
+    from . import dist as ldist
+    n = len(data)
+    lo, hi = ldist.shard_range(n, ctx.rank, ctx.world_size)
+    x = data.to_device(device, rows=(lo, hi)) if isinstance(data, EmbDataset) else data[lo:hi].to(device)
+    idx, resid_last, ks = assign_fn(x)
+    return ctx.gather_rows(idx), ctx.gather_rows(resid_last), ks
+
+
+def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True, ctx=None):
+    """Whole flow of generate_indices.py:51-145.  Returns a dict of the statistics it prints.
+
+    Under torchrun (ctx = dist.init_from_env()) pass 1 is item-sharded over the ranks; the conflict
+    rounds -- a few ms each, deterministic -- then run on every rank and rank 0 writes the file."""
+    from . import dist as ldist
+    ctx = ctx or ldist.current()
+    lead = ctx.rank == 0
+    verbose = verbose and lead
     ckpt = load_checkpoint(ckpt_path)
     args = ckpt["args"]
-    data = EmbDataset(data_path or args.data_path)
+    data = EmbDataset(data_path or args.data_path, mmap=ctx.enabled)
     model = build_model_from_args(args, data.dim)
     model.load_state_dict(ckpt["state_dict"])
     model = model.to(torch.device(device)).eval()
     if verbose:
         print(model)
-    x = data.to_device(device)
-    idx, resid_last, ks = assign_all(model, x)
-    first_pass = idx.tolist()
+    idx, resid_last, ks = sharded_assign(ctx, data, lambda x: assign_all(model, x), device)
+    first_pass = idx.clone()
 
-    def show(round_no, groups):
+    def show(round_no, n_groups):
         if verbose:
-            print(len(groups))
+            print(n_groups)
 
     idx, history = resolve_collisions(model, idx, resid_last, ks, on_round=show)
-    rows = idx.tolist()
-    _warn_if_reference_would_truncate(first_pass, rows)
+    _warn_if_reference_would_truncate(first_pass, idx)
     final = ops.collision_groups(idx, ks, want_groups=False)
-    n = len(rows)
+    n = idx.shape[0]
     stats = {"items": n, "max_conflicts": final["max_count"], "collision_rate": (n - final["unique"]) / n if n else 0.0,
              "rounds": len(history), "groups_per_round": history}
     if verbose:
         print("All indices number: ", n)
         print("Max number of conflicts: ", stats["max_conflicts"])
         print("Collision Rate", stats["collision_rate"])
-    os.makedirs(os.path.dirname(os.path.abspath(output_file)), exist_ok=True)
-    dump_index_json(rows, output_file)
+    if lead:
+        os.makedirs(os.path.dirname(os.path.abspath(output_file)), exist_ok=True)
+        dump_index_json(idx, output_file)
+    ctx.barrier()
     return stats
 
 
@@ -215,8 +248,13 @@ def main(argv=None):
     ap.add_argument("--data_path", type=str, default=None, help="override the data path stored in the checkpoint")
     ap.add_argument("--device", type=str, default="cuda:0")
     a = ap.parse_args(argv)
+    from . import dist as ldist
+    ctx = ldist.init_from_env(a)                       # torchrun: one rank per GPU; plain python: inert
     out = os.path.join(a.output_dir, f"{a.dataset}.index.json")
-    return generate(a.ckpt_path, out, device=a.device, data_path=a.data_path)
+    try:
+        return generate(a.ckpt_path, out, device=a.device, data_path=a.data_path, ctx=ctx)
+    finally:
+        ldist.shutdown(ctx)
 
 
 if __name__ == "__main__":

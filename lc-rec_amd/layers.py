@@ -156,14 +156,70 @@ class MLPLayers(nn.Module):
         return x.reshape(*input_feature.shape[:-1], x.shape[-1])
 
 
+KMEANS_IMPL = "sklearn"          # "sklearn" (the reference's host call) or "device"; main.py --kmeans_impl
+
+
 def kmeans(samples, num_clusters, num_iters=10):
     """layers.py:69-82: sklearn KMeans on the host (k-means++ from numpy's global RNG), centres
     returned on the samples' device.  Runs once per level per training run; the sklearn call is the
-    reference's own behaviour and its result is not bit-pinned."""
+    reference's own behaviour and its result is not bit-pinned.
+    With KMEANS_IMPL == "device" the clustering stays in HBM (kmeans_device)."""
+    if KMEANS_IMPL == "device":
+        return kmeans_device(samples, num_clusters, num_iters)
     from sklearn.cluster import KMeans
     x = samples.detach().cpu().numpy()
     cluster = KMeans(n_clusters=num_clusters, max_iter=num_iters).fit(x)
     return torch.from_numpy(cluster.cluster_centers_).to(samples.device)
+
+
+@torch.no_grad()
+def kmeans_pp_seed(x, num_clusters, generator=None):
+    """k-means++ seeding on the device: the first centre uniformly, every next one with probability
+    proportional to the squared distance to the nearest centre chosen so far (one draw per centre; sklearn's
+    greedy variant tries 2 + log K candidates per centre).  All draws come from `generator` (a device
+    generator; default: one seeded from torch's global CPU generator, so torch.manual_seed governs it)."""
+    n = x.shape[0]
+    if generator is None:
+        generator = torch.Generator(device=x.device)
+        generator.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+    first = torch.randint(n, (1,), device=x.device, generator=generator)
+    picks = [first]
+    nearest = ((x - x[first]) ** 2).sum(1)
+    for _ in range(1, num_clusters):
+        w = nearest.clamp_min(0)
+        if float(w.sum()) <= 0:                 # fewer distinct points than clusters: fall back to uniform
+            w = torch.ones_like(w)
+        nxt = torch.multinomial(w, 1, generator=generator)
+        picks.append(nxt)
+        nearest = torch.minimum(nearest, ((x - x[nxt]) ** 2).sum(1))
+    return x[torch.cat(picks)].clone()
+
+
+@torch.no_grad()
+def kmeans_device(samples, num_clusters, num_iters=10, tol=1e-4, generator=None, init=None):
+    """Device-resident replacement for the host sklearn call of layers.py:69-82 (SURVEY.md section 8f,
+    rank 3): k-means++ seeding, then Lloyd iterations made of the library's own kernels --
+    lcrec_rq_assign (one level) for the nearest centre and lcrec_code_stats for the per-cluster sums, both
+    deterministic, so a run is reproducible bit for bit and equals oracle/cpu_oracle.kmeans_lloyd from the
+    same seeds.  Stops after num_iters iterations or when the summed squared centre shift falls below
+    tol * mean feature variance (sklearn's rule).  An empty cluster keeps its centre (sklearn moves it to
+    a far point).  Not bit-comparable with sklearn -- nor is sklearn with itself across versions; the
+    reference's init is "parity unpinned" (SURVEY.md section 8c)."""
+    x = samples.detach().to(torch.float32).contiguous()
+    if not x.is_cuda:
+        raise ops._lib.LcrecError("kmeans_device expects a device tensor (lcrec_amd has no CPU path)")
+    centres = (kmeans_pp_seed(x, num_clusters, generator) if init is None
+               else init.detach().to(device=x.device, dtype=torch.float32).clone())
+    limit = tol * x.var(dim=0, unbiased=False).mean()
+    for _ in range(int(num_iters)):
+        idx = ops.rq_assign(x, centres.reshape(-1), [num_clusters])[0]
+        count, total = ops.code_stats(idx[:, 0], x, num_clusters)
+        moved = torch.where(count[:, None] > 0, total / count[:, None].clamp_min(1.0), centres)
+        shift = ((moved - centres) ** 2).sum()
+        centres = moved
+        if bool(shift <= limit):
+            break
+    return centres
 
 
 @torch.no_grad()

@@ -65,7 +65,11 @@ def parse_args(argv=None):
     # additions
     parser.add_argument("--no_bn", action="store_true", help="force bn=False (the bool flag cannot)")
     parser.add_argument("--no_kmeans_init", action="store_true", help="force kmeans_init=False")
+    parser.add_argument("--kmeans_impl", type=str, default="sklearn", choices=["sklearn", "device"],
+                        help="sklearn = the reference's host KMeans call; device = k-means++/Lloyd in HBM")
     args = parser.parse_args(argv)
+    from . import layers
+    layers.KMEANS_IMPL = args.kmeans_impl
     if args.no_bn:
         args.bn = False
     if args.no_kmeans_init:

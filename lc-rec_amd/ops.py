@@ -245,8 +245,11 @@ def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps):
 def collision_groups(idx, ks, want_groups=True):
     """Tuple collisions of an int64 [n, L] index matrix (trainer.py:139-150, generate_indices.py:18-42).
 
-    Returns dict(unique, max_count, collision_rate) and, with want_groups, `groups`: a list of
-    item-id lists in get_collision_item's order (first occurrence of the tuple; ids ascending)."""
+    Returns dict(unique, max_count, collision_rate, n_groups) and, with want_groups, the groups in
+    get_collision_item's order (first occurrence of the tuple; ids ascending inside a group):
+      want_groups=True      `groups`: a list of item-id lists (small inputs, tests, the reference's helper API);
+      want_groups="device"  `members` int64 [items in groups] and `offsets` int64 [n_groups + 1] device
+                            tensors -- group g = members[offsets[g]:offsets[g+1]] -- no Python lists."""
     lib = _lib.load()
     if not (idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 2):
         raise _lib.LcrecError("idx must be an int64 [n, L] device tensor")
@@ -266,10 +269,34 @@ def collision_groups(idx, ks, want_groups=True):
     c = counters.tolist()
     out = {"unique": c[0], "max_count": c[3], "collision_rate": (n - c[0]) / n if n else 0.0}
     if want_groups:
-        offs = offsets[: c[1] + 1].tolist()
-        mem = members[: c[2]].tolist()
-        out["groups"] = [mem[offs[g]:offs[g + 1]] for g in range(c[1])]
+        out["n_groups"] = c[1]
+        if want_groups == "device":
+            out["members"] = members[: c[2]]
+            out["offsets"] = offsets[: c[1] + 1]
+        else:
+            offs = offsets[: c[1] + 1].tolist()
+            mem = members[: c[2]].tolist()
+            out["groups"] = [mem[offs[g]:offs[g + 1]] for g in range(c[1])]
     return out
+
+
+def index_json_text(idx_rows, first_item=0):
+    """bytes of the `.index.json` entries of items first_item.. for a HOST int64 [n, L] array
+    (generate_indices.py:83-92,138-145; see lcrec_index_json_format in include/lcrec.h)."""
+    import numpy as np
+    lib = _lib.load()
+    a = np.ascontiguousarray(idx_rows, dtype=np.int64)
+    if a.ndim != 2:
+        raise _lib.LcrecError("idx_rows must be [n, L]")
+    n, L = a.shape
+    if n == 0:
+        return b""
+    cap = lib.lcrec_index_json_bound(n, L)
+    buf = np.empty(cap, dtype=np.uint8)
+    got = lib.lcrec_index_json_format(a.ctypes.data, n, L, int(first_item), buf.ctypes.data, cap)
+    if got < 0:
+        _lib.check(int(got), "lcrec_index_json_format")
+    return buf[:got].tobytes()
 
 
 def trace_enable(on=True):

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import dist as ldist
 from . import ops
-from .layers import kmeans
+from . import layers
 from .quantize import quantize
 
 
@@ -58,10 +58,10 @@ class VectorQuantizer(nn.Module):
             data = world.gather_rows(data.contiguous())
             centers = torch.zeros_like(self.embedding.weight.data)
             if world.rank == 0:
-                centers.copy_(kmeans(data, self.n_e, self.kmeans_iters))
+                centers.copy_(layers.kmeans(data, self.n_e, self.kmeans_iters))
             world.broadcast_(centers, src=0)
         else:
-            centers = kmeans(data, self.n_e, self.kmeans_iters)
+            centers = layers.kmeans(data, self.n_e, self.kmeans_iters)
         self.embedding.weight.data.copy_(centers)
         self.initted = True
 

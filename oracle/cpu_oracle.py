@@ -202,3 +202,26 @@ def distances(z, codebook):
     rc = fn(_p(z), n, e, _p(cb), K, _p(d))
     assert rc == 0, rc
     return d
+
+
+def kmeans_lloyd(x, init, iters, tol=1e-4):
+    """Lloyd iterations from given centres -- the checker for lcrec_amd.layers.kmeans_device (which
+    replaces the sklearn call of the reference's index/models/layers.py:69-82; that call itself is not
+    bit-pinned).  Nearest centre by the canonical distance (rq_assign, one level), per-cluster sums in
+    item order (code_stats), centre = sum / count in fp32, empty clusters keep their centre; stop when the
+    summed squared shift <= tol * mean feature variance.  Returns (centres, iterations run)."""
+    x = _f32(x)
+    c = _f32(init).copy()
+    K = c.shape[0]
+    limit = np.float32(tol) * x.var(axis=0, dtype=np.float32).mean(dtype=np.float32)
+    done = 0
+    for _ in range(int(iters)):
+        idx = rq_assign(x, [c])["idx"][:, 0]
+        count, total = code_stats(idx, x, K)
+        moved = np.where(count[:, None] > 0, total / np.maximum(count[:, None], np.float32(1.0)), c).astype(np.float32)
+        shift = ((moved - c) ** 2).sum(dtype=np.float32)
+        c = moved
+        done += 1
+        if shift <= limit:
+            break
+    return c, done

@@ -69,6 +69,33 @@ def _worker(rank, world, port, tmp):
         assert torch.equal(part, whole[rank * per:(rank + 1) * per])
     assert ldist.shard_range(10, rank, world) == ((0, 5) if rank == 0 else (5, 10))
     assert ldist.shard_range(7, 1, 4) == (2, 4) and ldist.shard_range(3, 3, 4) == (3, 3)
+
+    # ---- index generation: sharded pass 1 + one gather == the single-process pass (the per-rank
+    # assignment is the CPU oracle here; on the GPU node it is lcrec_encode_assign)
+    from lcrec_amd import generate_indices as gen
+    from lcrec_amd.datasets import EmbDataset
+    from oracle import cpu_oracle
+    rs = np.random.RandomState(3)
+    items = rs.standard_normal((37, 16)).astype(np.float32)
+    cbs = rs.standard_normal((2, 8, 16)).astype(np.float32)
+
+    def assign(x):
+        out = cpu_oracle.rq_assign(x.numpy(), list(cbs), want_resid=True)
+        return torch.from_numpy(out["idx"]), torch.from_numpy(out["resid"][1].copy()), [8, 8]
+
+    whole_idx, whole_res, _ = assign(torch.from_numpy(items))
+    got_idx, got_res, ks = gen.sharded_assign(ctx, torch.from_numpy(items), assign, "cpu")
+    assert torch.equal(got_idx, whole_idx) and torch.equal(got_res, whole_res) and ks == [8, 8]
+    path = os.path.join(tmp, "items.npy")
+    if rank == 0:
+        np.save(path, items.astype(np.float64))          # the loader casts to fp32 (datasets.py:19)
+    ctx.barrier()
+    got_idx2, _, _ = gen.sharded_assign(ctx, EmbDataset(path, mmap=True), assign, "cpu")
+    assert torch.equal(got_idx2, whole_idx)
+    ctx.barrier()
+    if rank == 0:
+        os.remove(path)
+
     with open(os.path.join(tmp, f"ok{rank}"), "w") as fh:
         fh.write("ok")
     ldist.shutdown(ctx)

@@ -119,3 +119,40 @@ def test_no_cpu_path(hip):
     model = hip.RQVAE(in_dim=128, num_emb_list=[256] * 2, e_dim=16, layers=[64], sk_epsilons=[0.0, 0.0])
     with pytest.raises(hip.LcrecError):
         model.eval().get_indices(torch.zeros(4, 128))
+
+
+def test_device_kmeans_matches_oracle_lloyd_and_is_reproducible(hip):
+    """layers.kmeans_device (replaces the sklearn call of layers.py:69-82, which
+    is itself not bit-pinned): Lloyd iterations equal oracle/cpu_oracle.kmeans_lloyd bit for bit from
+    the same initial centres; seeding is reproducible from its generator and improves on random rows."""
+    from lcrec_amd import layers
+    from oracle import cpu_oracle
+    rs = gi.rs(77)
+    blobs = rs.standard_normal((24, 32)) * 3.0
+    x = gi.f32(blobs[rs.randint(0, 24, size=3000)] + 0.3 * rs.standard_normal((3000, 32)))
+    xd = torch.from_numpy(x).to(DEV)
+    init = x[rs.choice(3000, size=64, replace=False)]
+    got = layers.kmeans_device(xd, 64, num_iters=7, tol=0.0, init=torch.from_numpy(init))
+    want, iters = cpu_oracle.kmeans_lloyd(x, init, 7, tol=0.0)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+    def inertia(c):
+        return float(torch.cdist(xd, c).min(1).values.pow(2).sum())
+
+    g1 = torch.Generator(device=DEV).manual_seed(5)
+    g2 = torch.Generator(device=DEV).manual_seed(5)
+    c1 = layers.kmeans_device(xd, 24, num_iters=100, generator=g1)
+    c2 = layers.kmeans_device(xd, 24, num_iters=100, generator=g2)
+    assert torch.equal(c1, c2) and bool(torch.isfinite(c1).all())
+    seed_only = layers.kmeans_pp_seed(xd, 24, torch.Generator(device=DEV).manual_seed(5))
+    assert inertia(c1) <= inertia(seed_only) < inertia(xd[:24])
+    # same entry point the quantiser calls when main.py is given --kmeans_impl device
+    layers.KMEANS_IMPL = "device"
+    try:
+        torch.manual_seed(3)
+        a = layers.kmeans(xd, 16, 20)
+        torch.manual_seed(3)
+        b = layers.kmeans(xd, 16, 20)
+        assert torch.equal(a, b) and a.shape == (16, 32)
+    finally:
+        layers.KMEANS_IMPL = "sklearn"

@@ -241,3 +241,30 @@ def test_index_json_is_what_the_downstream_reader_expects(tmp_path):
     new_tokens = sorted({t for toks in index.values() for t in toks})
     assert all(re.fullmatch(r"<[a-d]_\d+>", t) for t in new_tokens)
     assert gen.tokens_for([[1] * 8])[0][5:] == ["<f_1>", "<g_1>", "<h_1>"]          # beyond the reference's 5 prefixes
+
+
+def test_native_index_json_text_equals_json_dump():
+    """lcrec_index_json_format (host-side text, no device work) against json.dumps of the reference's
+    dict-of-token-lists (generate_indices.py:83-92,138-145): single-thread and sliced paths, L up to 26,
+    wide and negative values, a non-zero first item, and the tight-buffer error."""
+    import ctypes
+    from lcrec_amd import _lib, ops, generate_indices as gen
+    rs = np.random.RandomState(0)
+    for n, L, hi in [(1, 1, 5), (3, 4, 256), (70000, 4, 256), (66000, 8, 1024), (5, 26, 2 ** 62), (0, 4, 256)]:
+        a = rs.randint(0, hi, size=(n, L), dtype=np.int64)
+        if n > 3:
+            a[2, 0] = -1
+        want = json.dumps({7 + i: gen.tokens_for([r])[0] for i, r in enumerate(a.tolist())})[1:-1].encode()
+        assert ops.index_json_text(a, first_item=7) == want, (n, L)
+    lib = _lib.load()
+    a = np.arange(40, dtype=np.int64).reshape(10, 4)
+    buf = ctypes.create_string_buffer(64)
+    assert lib.lcrec_index_json_format(a.ctypes.data, 10, 4, 0, ctypes.addressof(buf), 64) == -3
+    assert b"too small" in lib.lcrec_last_error()
+    assert lib.lcrec_index_json_format(a.ctypes.data, 10, 27, 0, ctypes.addressof(buf), 64) == -1
+    # tight (but sufficient) buffer: the checked single-pass path gives the same bytes
+    want = json.dumps({i: gen.tokens_for([r])[0] for i, r in enumerate(a.tolist())})[1:-1].encode()
+    cap = len(want) + 140
+    buf = ctypes.create_string_buffer(cap)
+    got = lib.lcrec_index_json_format(a.ctypes.data, 10, 4, 0, ctypes.addressof(buf), cap)
+    assert buf.raw[:got] == want
