@@ -271,8 +271,11 @@ __global__ __launch_bounds__(SK_THREADS) void sk_final_kernel(SkBig p, int src, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Sinkhorn, many small independent problems (collision groups of generate_indices.py:113-119):
-// one workgroup per group, the whole g x K matrix in LDS (g*K <= SKS_MAX doubles).
+// Sinkhorn, many independent problems (collision groups of generate_indices.py:113-119): one
+// workgroup per group.  The g x K fp64 matrix lives in LDS when it fits (g*K <= SKS_MAX doubles; launches
+// are bucketed by size so that pairs and triples -- the bulk -- are not charged a 128 KB allocation),
+// otherwise in this group's slice of a workspace slab in HBM/L2 (GLOBALQ): the few-hundred-row groups a
+// collision-heavy round produces then run side by side instead of ~50 launches each, one after another.
 // ------------------------------------------------------------------------------------------
 constexpr int SKS_MAX = 16384;   // doubles of LDS for Q (128 KB)
 constexpr int SKS_THREADS = 256;
@@ -288,19 +291,21 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
     return s;
 }
 
-template <int E>
+template <int E, bool GLOBALQ>
 __global__ __launch_bounds__(SKS_THREADS) void sk_small_kernel(const float *__restrict__ r, const float *__restrict__ cb,
                                                               int K, const int64_t *__restrict__ offs,
                                                               double eps, int iters, int64_t *idx_out,
-                                                              int64_t idx_stride)
+                                                              int64_t idx_stride, double *qslab)
 {
     extern __shared__ __attribute__((aligned(16))) double sks_sm[];
     __shared__ double scratch[SKS_THREADS / 64];
     __shared__ float fred[2][SKS_THREADS / 64];
-    const int64_t i0 = offs[2 * blockIdx.x];           // offs holds (begin, end) pairs
-    const int g = (int)(offs[2 * blockIdx.x + 1] - i0);
+    const int64_t i0 = offs[3 * blockIdx.x];           // offs holds (begin, end, slab offset in doubles) triples
+    const int g = (int)(offs[3 * blockIdx.x + 1] - i0);
     if (g <= 0) return;
-    double *Q = sks_sm;                          // [g][K]
+    // (a workgroup's global-memory traffic is ordered by __syncthreads just like its LDS traffic: all its
+    // waves share one CU, hence one L1)
+    double *Q = GLOBALQ ? qslab + offs[3 * blockIdx.x + 2] : sks_sm;   // [g][K]
     double *rsum = Q + (size_t)g * K;            // [g]
     double *csum = rsum + ((g + 1) & ~1);        // [K]
     float *dmat = reinterpret_cast<float *>(Q);  // fp32 distances alias the front half of Q first
@@ -536,15 +541,41 @@ static size_t sk_big_bytes(int64_t B, int K)
            align_up((size_t)2 * nblk * K * sizeof(double), 256) + align_up((size_t)nblk * sizeof(double), 256) + 256;
 }
 
-size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G)
+// Size classes of a group of sz rows (see sinkhorn_assign): 0 = tiny (Q <= 16 KB of LDS), 1 = fits the
+// LDS budget, 2 = Q in the workspace slab, one workgroup per group, 3 = batch-sized (multi-launch / persistent).
+constexpr int64_t SKS_TINY = 2048;              // doubles: groups of <= 8 items at K = 256
+constexpr int64_t SKS_SLAB_MAX_ROWS = 4096;     // a larger group is a training-batch-sized problem
+
+static inline size_t sk_group_doubles(int64_t g, int K) { return (size_t)g * K + (size_t)((g + 1) & ~(int64_t)1) + K; }
+
+static inline int sk_class(int64_t sz, int K)
 {
-    int64_t biggest = 0;
+    if (sz * K <= SKS_TINY) return 0;
+    if (sz * K <= SKS_MAX) return 1;
+    return sz <= SKS_SLAB_MAX_ROWS ? 2 : 3;
+}
+
+struct SkPlan { int64_t slab_doubles; int64_t biggest; int n_slab; };
+
+static SkPlan sk_plan(int K, const int64_t *offs, int G)
+{
+    SkPlan p = {0, 0, 0};
     for (int g = 0; g < G; ++g) {
         const int64_t sz = offs[g + 1] - offs[g];
-        if (sz * K > SKS_MAX && sz > biggest) biggest = sz;
+        if (sz <= 0) continue;
+        const int cls = sk_class(sz, K);
+        if (cls == 2) { p.slab_doubles += (int64_t)sk_group_doubles(sz, K); ++p.n_slab; }
+        if (cls == 3 && sz > p.biggest) p.biggest = sz;
     }
+    return p;
+}
+
+size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G)
+{
     (void)n;
-    return align_up((size_t)2 * G * sizeof(int64_t), 256) + (biggest ? sk_big_bytes(biggest, K) : 0);
+    const SkPlan p = sk_plan(K, offs, G);
+    return align_up((size_t)3 * G * sizeof(int64_t), 256) + align_up((size_t)p.slab_doubles * sizeof(double), 256) +
+           (p.biggest ? sk_big_bytes(p.biggest, K) : 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -803,18 +834,29 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     return check_launch("sinkhorn kernels");
 }
 
-template <int E>
-static int launch_sk_small(const float *r, const float *cb, int K, const int64_t *offs_dev, int G, int maxg, double eps,
-                           int iters, int64_t *idx_out, int64_t idx_stride, hipStream_t stream)
+template <int E, bool GLOBALQ>
+static int launch_sk_small(const float *r, const float *cb, int K, const int64_t *triples_dev, int G, int maxg, double eps,
+                           int iters, int64_t *idx_out, int64_t idx_stride, double *qslab, hipStream_t stream)
 {
-    const size_t lds = ((size_t)maxg * K + ((maxg + 1) & ~1) + K) * sizeof(double);
-    auto kern = sk_small_kernel<E>;
-    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(he));
+    const size_t lds = GLOBALQ ? 0 : sk_group_doubles(maxg, K) * sizeof(double);
+    auto kern = sk_small_kernel<E, GLOBALQ>;
+    if (lds > 48 * 1024) {
+        hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(he));
+    }
     TraceScope trace(K_SINKHORN_SMALL, stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(SKS_THREADS), lds, stream, r, cb, K, offs_dev, eps, iters, idx_out,
-                       idx_stride);
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(SKS_THREADS), lds, stream, r, cb, K, triples_dev, eps, iters, idx_out,
+                       idx_stride, qslab);
     return check_launch("sk_small_kernel");
+}
+
+template <bool GLOBALQ>
+static int launch_sk_small_e(int e, const float *r, const float *cb, int K, const int64_t *triples_dev, int G, int maxg,
+                             double eps, int iters, int64_t *idx_out, int64_t idx_stride, double *qslab, hipStream_t stream)
+{
+    if (e == 16) return launch_sk_small<16, GLOBALQ>(r, cb, K, triples_dev, G, maxg, eps, iters, idx_out, idx_stride, qslab, stream);
+    if (e == 32) return launch_sk_small<32, GLOBALQ>(r, cb, K, triples_dev, G, maxg, eps, iters, idx_out, idx_stride, qslab, stream);
+    return launch_sk_small<64, GLOBALQ>(r, cb, K, triples_dev, G, maxg, eps, iters, idx_out, idx_stride, qslab, stream);
 }
 
 int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
@@ -832,36 +874,48 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
     const size_t need = sinkhorn_workspace(n, K, offs, G);
     if (!workspace || workspace_bytes < need)
         return fail(LCREC_EWORKSPACE, "sinkhorn_assign: workspace %zu B < required %zu B", workspace_bytes, need);
+    const SkPlan plan = sk_plan(K, offs, G);
     char *ws = reinterpret_cast<char *>(workspace);
-    int64_t *pairs_dev = reinterpret_cast<int64_t *>(ws);
-    ws += align_up((size_t)2 * G * sizeof(int64_t), 256);
+    int64_t *triples_dev = reinterpret_cast<int64_t *>(ws);
+    ws += align_up((size_t)3 * G * sizeof(int64_t), 256);
+    double *qslab = reinterpret_cast<double *>(ws);
+    ws += align_up((size_t)plan.slab_doubles * sizeof(double), 256);
 
-    // groups whose g x K matrix fits in LDS run together, one workgroup each
-    std::vector<int64_t> pairs;
-    int maxg = 0;
-    for (int g = 0; g < G; ++g) {
-        const int64_t sz = offs[g + 1] - offs[g];
-        if (sz > 0 && sz * K <= SKS_MAX) {
-            pairs.push_back(offs[g]);
-            pairs.push_back(offs[g + 1]);
-            if (sz > maxg) maxg = (int)sz;
+    // Size classes, one launch each: [0] tiny and [1] LDS-sized groups keep Q in LDS, [2] mid-sized
+    // groups keep it in their slice of the slab; anything larger is a batch-sized problem (below).
+    std::vector<int64_t> triples;
+    triples.reserve((size_t)3 * G);
+    int count[3] = {0, 0, 0}, maxg[3] = {0, 0, 0};
+    for (int cls = 0; cls < 3; ++cls) {
+        int64_t slab = 0;
+        for (int g = 0; g < G; ++g) {
+            const int64_t sz = offs[g + 1] - offs[g];
+            if (sz <= 0 || sk_class(sz, K) != cls) continue;
+            triples.push_back(offs[g]);
+            triples.push_back(offs[g + 1]);
+            triples.push_back(cls == 2 ? slab : 0);
+            if (cls == 2) slab += (int64_t)sk_group_doubles(sz, K);
+            ++count[cls];
+            if (sz > maxg[cls]) maxg[cls] = (int)sz;
         }
     }
-    if (!pairs.empty()) {
-        hipError_t he = hipMemcpyAsync(pairs_dev, pairs.data(), sizeof(int64_t) * pairs.size(), hipMemcpyHostToDevice, stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(stream);   // pairs is a host temporary
+    if (!triples.empty()) {
+        hipError_t he = hipMemcpyAsync(triples_dev, triples.data(), sizeof(int64_t) * triples.size(), hipMemcpyHostToDevice, stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(stream);   // triples is a host temporary
         if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn_assign: %s", hipGetErrorString(he));
-        const int nb = (int)(pairs.size() / 2);
-        int rc;
-        if (e == 16) rc = launch_sk_small<16>(r, cb, K, pairs_dev, nb, maxg, eps, iters, idx_out, idx_stride, stream);
-        else if (e == 32) rc = launch_sk_small<32>(r, cb, K, pairs_dev, nb, maxg, eps, iters, idx_out, idx_stride, stream);
-        else rc = launch_sk_small<64>(r, cb, K, pairs_dev, nb, maxg, eps, iters, idx_out, idx_stride, stream);
-        if (rc) return rc;
+        const int64_t *t = triples_dev;
+        for (int cls = 0; cls < 3; ++cls) {
+            if (!count[cls]) continue;
+            int rc = cls == 2 ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab, stream)
+                              : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, stream);
+            if (rc) return rc;
+            t += (size_t)3 * count[cls];
+        }
     }
     // larger problems (a training batch) go through the multi-launch path, one at a time
     for (int g = 0; g < G; ++g) {
         const int64_t sz = offs[g + 1] - offs[g];
-        if (sz * K > SKS_MAX) {
+        if (sz > 0 && sk_class(sz, K) == 3) {
             int rc = sinkhorn_big(r + offs[g] * e, sz, e, cb, K, eps, iters, idx_out + offs[g] * idx_stride, idx_stride, ws, stream);
             if (rc) return rc;
         }

@@ -165,19 +165,20 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
     codebook = _dev(codebook, "codebook")
     n, e = resid.shape
     K = codebook.shape[0]
-    offs = [0, n] if group_offsets is None else [int(v) for v in group_offsets]
+    import numpy as np
+    offs = np.ascontiguousarray([0, n] if group_offsets is None else group_offsets, dtype=np.int64)
     G = len(offs) - 1
     if out is None:
         out = torch.zeros(n, dtype=torch.int64, device=resid.device)
     out, stride = _idx_col(out, n)
-    oarr = (ctypes.c_int64 * len(offs))(*offs)
+    oarr = offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
     with torch.cuda.device(resid.device):
         nbytes = lib.lcrec_sinkhorn_assign_workspace(n, K, oarr, G)
         ws = _workspace(nbytes, resid.device)
         rc = lib.lcrec_sinkhorn_assign(_ptr(resid), n, e, _ptr(codebook), K, oarr, G, float(epsilon), int(iters),
                                        _ptr(out), stride, _ptr(ws), ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_sinkhorn_assign")
-    if any((b - a) * K > 16384 for a, b in zip(offs[:-1], offs[1:])):
+    if G > 0 and int(np.diff(offs).max()) * K > 16384:
         # the one-launch solver for batch-sized problems poisons its output with -1 if its (bounded)
         # grid barrier ever times out; turn that into an error here rather than training on garbage
         if bool((out < 0).any()):

@@ -101,3 +101,53 @@ def test_deep_residual_8x1024_properties(hip, oracle):
     # 80-bit tuples: collision statistics vs torch.unique over rows
     got = hip.ops.collision_groups(idx, ks, want_groups=False)
     assert got["unique"] == torch.unique(idx, dim=0).shape[0]
+
+
+def test_conflict_resolution_at_scale_properties(hip, tmp_path):
+    """generate_indices.py:101-145 on 400 k items with a deliberately small code space (3 x 64 = 262 144
+    tuples), so that tens of thousands of collision groups go through every round: the batched
+    device rounds against per-group calls, the untouched prefix levels, and the emitted file."""
+    import json
+    from lcrec_amd import generate_indices as gen
+    n, in_dim, L, K = 400_000, 64, 3, 64
+    torch.manual_seed(9)
+    model = hip.RQVAE(in_dim=in_dim, num_emb_list=[K] * L, e_dim=32, layers=[64], kmeans_init=False,
+                      sk_epsilons=[0.0] * L, sk_iters=50).to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn((n, in_dim), generator=g, device=DEV)
+    with torch.no_grad():
+        z = model.encoder(x[:20000])
+    for l, cb in enumerate(_codebooks(hip, z, [K] * L, g)):
+        model.rq.vq_layers[l].embedding.weight.data.copy_(cb)
+    idx0, resid_last, ks = gen.assign_all(model, x, chunk_rows=150_000)
+    assert torch.equal(idx0, model.get_indices(x))
+    first = hip.ops.collision_groups(idx0, ks, want_groups="device")
+    assert first["n_groups"] > 10_000
+    # round 1, group by group (the reference's loop shape) for a sample of groups == the batched round
+    offs = first["offsets"].cpu().numpy()
+    cb_last = model.rq.vq_layers[-1].embedding.weight.detach().contiguous()
+    rounds = []
+    idx, history = gen.resolve_collisions(model, idx0.clone(), resid_last, ks, max_rounds=1,
+                                          on_round=lambda r, k: rounds.append(k))
+    assert history == rounds == [first["n_groups"]]
+    for gi_ in list(range(0, first["n_groups"], max(1, first["n_groups"] // 40)))[:40]:
+        mem = first["members"][offs[gi_]:offs[gi_ + 1]]
+        alone = hip.ops.sinkhorn_assign(resid_last[mem], cb_last, 0.003, 50)
+        assert torch.equal(alone, idx[mem, L - 1])
+    outside = torch.ones(n, dtype=torch.bool, device=DEV)
+    outside[first["members"]] = False
+    assert torch.equal(idx[outside], idx0[outside])                   # items outside every group keep their tuple
+    # all 20 rounds: prefix levels never change, uniqueness improves, statistics agree with torch.unique
+    idx, history = gen.resolve_collisions(model, idx0.clone(), resid_last, ks)
+    assert 1 <= len(history) <= 20 and history[0] == first["n_groups"]
+    assert torch.equal(idx[:, :L - 1], idx0[:, :L - 1])
+    final = hip.ops.collision_groups(idx, ks, want_groups=False)
+    assert final["unique"] == torch.unique(idx, dim=0).shape[0] and final["unique"] > first["unique"]
+    # the file: json.load accepts it, item order, tokens
+    path = str(tmp_path / "big.index.json")
+    gen.dump_index_json(idx, path, chunk_items=150_000)
+    index = json.load(open(path))
+    assert len(index) == n and list(index)[:3] == ["0", "1", "2"] and list(index)[-1] == str(n - 1)
+    rows = idx.cpu().numpy()
+    for i in (0, 1, 149_999, 150_000, 150_001, n - 1):
+        assert index[str(i)] == gen.tokens_for([rows[i].tolist()])[0]

@@ -167,8 +167,10 @@ def test_sinkhorn_collision_groups(hip, K, e):
     rs = _rs(K + e)
     cap = max(2, min(40, 16384 // K))
     sizes = list(rs.randint(2, cap + 1, size=60)) + [1, 2, cap]
+    # groups too large for LDS keep Q in the workspace slab, still one workgroup each and side by side
+    sizes += {256: [65, 300, 700], 16: [1500, 1025], 1024: [17, 130]}[K]
     if K == 16:
-        sizes.append(1500)       # one group too large for LDS: goes through the multi-launch path
+        sizes.append(5000)       # beyond the slab limit: a batch-sized problem, multi-launch path
     offs = np.concatenate([[0], np.cumsum(sizes)])
     n = int(offs[-1])
     z = rs.standard_normal((n, e)).astype(np.float32)

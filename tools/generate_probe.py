@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Wall-clock of the index-emission flow (generate_indices.py:51-145) at BASELINE sizes on one GPU:
+pass 1 (encode + assign), the conflict rounds, the .index.json text.
+
+    python tools/generate_probe.py [--items 1000000] [--in_dim 768] [--levels 4] [--codes 256]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lcrec_amd  # noqa: E402
+from lcrec_amd import generate_indices as gen, ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--in_dim", type=int, default=768)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--codes", type=int, default=256)
+    ap.add_argument("--out", type=str, default="/tmp/probe.index.json")
+    a = ap.parse_args()
+    dev = "cuda:0"
+    torch.manual_seed(2024)
+    model = lcrec_amd.RQVAE(in_dim=a.in_dim, num_emb_list=[a.codes] * a.levels, e_dim=32,
+                            layers=[2048, 1024, 512, 256, 128, 64], kmeans_init=False,
+                            sk_epsilons=[0.0] * a.levels, sk_iters=50).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(2024)
+    x = torch.randn((a.items, a.in_dim), generator=g, device=dev)
+    with torch.no_grad():
+        z = model.encoder(x[:65536])
+        resid = z
+        for l in range(a.levels):                          # data-scale codebooks: rows of the level's residuals
+            cb = resid[torch.randperm(resid.shape[0], generator=g, device=dev)[:a.codes]].clone()
+            model.rq.vq_layers[l].embedding.weight.data.copy_(cb)
+            resid = resid - cb[ops.rq_assign(resid.contiguous(), cb.reshape(-1), [a.codes])[0][:, 0]]
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    gen.assign_all(model, x[:4096])
+    (idx, resid_last, ks), t_pass1 = timed(lambda: gen.assign_all(model, x))
+    first = ops.collision_groups(idx, ks, want_groups=False)
+    ops.trace_enable(True)
+    (idx, history), t_rounds = timed(lambda: gen.resolve_collisions(model, idx, resid_last, ks))
+    trace = ops.trace_collect()
+    ops.trace_enable(False)
+    final = ops.collision_groups(idx, ks, want_groups=False)
+    _, t_json = timed(lambda: gen.dump_index_json(idx, a.out))
+    size = os.path.getsize(a.out)
+    os.remove(a.out)
+    print(f"items {a.items}  in_dim {a.in_dim}  {a.levels} x {a.codes} codes")
+    print(f"pass 1 (encode+assign)   {t_pass1 * 1e3:9.1f} ms   {a.items / t_pass1 / 1e6:7.2f} M items/s")
+    print(f"conflict rounds ({len(history):2d})     {t_rounds * 1e3:9.1f} ms   groups/round {history[:6]}{' ...' if len(history) > 6 else ''}")
+    print("  kernels: " + ", ".join(f"{k} {v[1]:.1f} ms/{v[0]}" for k, v in sorted(trace.items(), key=lambda kv: -kv[1][1])))
+    print(f"  collision rate {first['collision_rate']:.6f} -> {final['collision_rate']:.6f}")
+    print(f".index.json ({size / 1e6:.0f} MB)     {t_json * 1e3:9.1f} ms   {a.items / t_json / 1e6:7.2f} M items/s (D2H + text + write)")
+
+
+if __name__ == "__main__":
+    main()
