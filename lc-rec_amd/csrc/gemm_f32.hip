@@ -270,7 +270,7 @@ struct StageRegsG {
     bool ok[ITERS];
 };
 
-template <int ROWS, int THREADS, bool FULL = false>
+template <int ROWS, int THREADS>
 __device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const float *__restrict__ src, int64_t row0,
                                              int64_t rows_total, int K, int k0, int t)
 {
@@ -280,15 +280,6 @@ __device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const
         const int row = p >> 2, kg = p & 3;
         const int64_t grow = row0 + row;
         const int k = k0 + kg * 8;
-        if constexpr (FULL) {
-            // interior tile (host-checked: every row and the whole K slice are in range): plain loads, no
-            // guards -- every instruction of the staging role steals MFMA issue slots (see the kernel)
-            static_assert(ROWS * 4 % THREADS == 0, "exact cover");
-            const f32x4 *g = reinterpret_cast<const f32x4 *>(src + grow * (int64_t)K + k);
-            r.v[it][0] = g[0];
-            r.v[it][1] = g[1];
-            continue;
-        }
         // branch-free: out-of-range lanes read a clamped (valid) address; the zero is selected when the
         // registers are written to LDS (stage_store_g), NOT here -- touching the loaded value now would
         // put the s_waitcnt in front of the MFMAs this load is meant to hide behind
@@ -300,7 +291,7 @@ __device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const
     }
 }
 
-template <int ROWS, int THREADS, bool FULL = false>
+template <int ROWS, int THREADS>
 __device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r, float *lds, int t)
 {
 #pragma unroll
@@ -309,7 +300,7 @@ __device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r
         const int row = p >> 2, kg = p & 3;
         if (row < ROWS) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 a = (FULL || r.ok[it]) ? r.v[it][0] : z, b = (FULL || r.ok[it]) ? r.v[it][1] : z;
+            const f32x4 a = r.ok[it] ? r.v[it][0] : z, b = r.ok[it] ? r.v[it][1] : z;
             f32x4 ev = {a[0], a[2], b[0], b[2]};
             f32x4 od = {a[1], a[3], b[1], b[3]};
             f32x4 *d = reinterpret_cast<f32x4 *>(lds + row * LDK + kg * 8);
@@ -319,7 +310,6 @@ __device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r
     }
 }
 
-template <bool FULL>
 __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
@@ -366,14 +356,13 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
     float *my_a = As[grp];
 
     // ---- prologue: W[0] (both halves) and A0[0] into LDS; group 1 leaves (A1[0], upper W[1]) in registers
-    stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, 0, gt);
-    stage_store_g<64, 256, FULL>(rw, Ws[0] + grp * 64 * LDK, gt);
-    stage_load_g<GM, 256, FULL>(ra, A, m0, M, K, 0, gt);
+    stage_load_g<64, 256>(rw, W, w_row0, N, K, 0, gt);
+    stage_store_g<64, 256>(rw, Ws[0] + grp * 64 * LDK, gt);
+    stage_load_g<GM, 256>(ra, A, m0, M, K, 0, gt);
     if (grp == 0) {
-        stage_store_g<GM, 256, FULL>(ra, my_a, gt);
+        stage_store_g<GM, 256>(ra, my_a, gt);
     } else {
-        // upper W[1]; the guard-free variant must not read past K (the generic one returns zeros there)
-        if (!FULL || nk > 1) stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, BK, gt);
+        stage_load_g<64, 256>(rw, W, w_row0, N, K, BK, gt);      // upper W[1] (zeros if nk == 1)
     }
     __syncthreads();
 
@@ -406,15 +395,11 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                 }
                 if (tune & (8 | 128)) {
                 } else if (half == 0) {
-                    // (tiles past the last one are never consumed: the guard-free variant skips their loads
-                    // instead of reading beyond K; the generic variant loads zeros)
-                    if (!FULL || u + 1 < nk) {
-                        stage_load_g<GM, 256, FULL>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A0[u+1]
-                        stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, (u + 1) * BK, gt);      // lower W[u+1]
-                    }
+                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A0[u+1]
+                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 1) * BK, gt);      // lower W[u+1]
                 } else {
-                    if (!FULL || u + 1 < nk) stage_load_g<GM, 256, FULL>(ra, A, m0, M, K, (u + 1) * BK, gt);     // A1[u+1]
-                    if (!FULL || u + 2 < nk) stage_load_g<64, 256, FULL>(rw, W, w_row0, N, K, (u + 2) * BK, gt); // upper W[u+2]
+                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A1[u+1]
+                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 2) * BK, gt);      // upper W[u+2]
                 }
                 if (!(tune & 32)) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -450,12 +435,12 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                 if (tune & (8 | 64)) {
                 } else if (half == 0) {
                     // group 1 in phase 2u: A1[u] (needed next phase) and the upper half of W[u+1]
-                    stage_store_g<GM, 256, FULL>(ra, my_a, gt);
-                    stage_store_g<64, 256, FULL>(rw, Ws[(u + 1) & 1] + 64 * LDK, gt);
+                    stage_store_g<GM, 256>(ra, my_a, gt);
+                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1] + 64 * LDK, gt);
                 } else {
                     // group 0 in phase 2u+1: A0[u+1] and the lower half of W[u+1]
-                    stage_store_g<GM, 256, FULL>(ra, my_a, gt);
-                    stage_store_g<64, 256, FULL>(rw, Ws[(u + 1) & 1], gt);
+                    stage_store_g<GM, 256>(ra, my_a, gt);
+                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1], gt);
                 }
                 LCREC_STAMP(1);
                 if (!(tune & 16)) __syncthreads();
@@ -477,6 +462,218 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
                              bn_shift, relu);
 }
 
+// ------------------------------------------------------------------------------------------
+// Ping-pong kernel, second form, for K % 32 == 0 (every layer of the run.sh architecture).
+// Same tile, same roles, same phase barriers and the same arithmetic as linear_fwd_pp_kernel; what
+// changes is WHICH ISSUE PORT the non-MFMA work uses.  In-kernel cycle stamps (tools/stamp_probe.py)
+// showed that a wave with back-to-back fp32 MFMAs queued keeps the SIMD's VALU port: its partner's
+// VALU instructions get through about once per 64-cycle MFMA, so a staging role made of
+// 48 v_mov (the k de-interleave) + 12 ds_write_b128 took 2 400 cycles instead of ~200 and the computing
+// wave sat 500-700 cycles per phase at the barrier waiting for it.  LDS, vector-memory and scalar
+// instructions issue on their own ports and are not held up.  So here:
+//   * the de-interleave is done by the LDS unit: ds_write2_b32 places any two registers at any two dword
+//     offsets, so (k0,k1) -> slots 0 and 4, (k2,k3) -> 1 and 5, ... : 24 LDS writes, zero VALU;
+//   * global loads are buffer loads: a scalar resource descriptor per tile (base = the tile's first row,
+//     extent = its valid rows), a per-thread byte offset that never changes, and the K-tile offset in an
+//     SGPR advanced by the scalar unit -- no VALU address arithmetic, and rows past M or N read as zero
+//     through the descriptor's range check instead of through compares and selects;
+//   * the K loop is unrolled by two so both W buffers are compile-time LDS offsets;
+//   * sched_barriers pin the second half's fragment reads under the first half's MFMAs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+// a = k..k+3, b = k+4..k+7 of one row -> the row's group of 8 in LDS: [k0 k2 k4 k6 | k1 k3 k5 k7]
+__device__ __forceinline__ void lds_store_deint8(uint32_t addr, const f32x4 &a, const f32x4 &b)
+{
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:4" ::"v"(addr), "v"(a[0]), "v"(a[1]) : "memory");
+    asm volatile("ds_write2_b32 %0, %1, %2 offset0:1 offset1:5" ::"v"(addr), "v"(a[2]), "v"(a[3]) : "memory");
+    asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:6" ::"v"(addr), "v"(b[0]), "v"(b[1]) : "memory");
+    asm volatile("ds_write2_b32 %0, %1, %2 offset0:3 offset1:7" ::"v"(addr), "v"(b[2]), "v"(b[3]) : "memory");
+}
+
+template <int N>
+struct IntC { static constexpr int value = N; };
+
+__global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
+    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int xcd_order)
+{
+    constexpr int GM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) float As[2][GM * LDK];
+    __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int gt = tid & 255;
+
+    int64_t bm;
+    int bn;
+    if (xcd_order) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int panels = (bm_blocks - xcd + 7) >> 3;
+        if (j >= panels * bn_blocks) return;
+        bm = (int64_t)(j / bn_blocks) * 8 + xcd;
+        bn = j % bn_blocks;
+    } else {
+        bm = blockIdx.x / bn_blocks;
+        bn = blockIdx.x % bn_blocks;
+    }
+    const int64_t m0 = bm * (2 * GM) + grp * GM;
+    const int n0 = bn * BN;
+    const int64_t w_row0 = n0 + grp * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    float *my_a = As[grp];
+
+    // global side: one buffer descriptor per operand tile (stride 0 = raw; extent = the tile's valid rows, so
+    // rows past the matrix read as 0.0f and an all-out-of-range tile touches no memory), a fixed per-thread
+    // byte offset (row gt/4, k-group gt%4), and the K-tile (and +64-row) byte offset in an SGPR
+    auto tile_rsrc = [&](const float *base, int64_t first_row, int64_t total_rows, int tile_rows) {
+        int64_t rows = total_rows - first_row;
+        rows = rows < 0 ? 0 : (rows > tile_rows ? tile_rows : rows);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + first_row * (int64_t)K), 0,
+                                                 (int)(rows * K * 4), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A, m0, M, GM);
+    const __amdgpu_buffer_rsrc_t w_rsrc = tile_rsrc(W, w_row0, N, 64);
+    const int t_g = ((gt >> 2) * K + (gt & 3) * 8) * 4;
+    const int row64 = 64 * K * 4;
+    // LDS side: this thread's 8-float slot in row gt/4 (+64) of a tile
+    const uint32_t t_s = (uint32_t)(((gt >> 2) * LDK + (gt & 3) * 8) * 4);
+    const uint32_t a_s0 = lds_addr(my_a) + t_s, a_s1 = a_s0 + 64 * LDK * 4;
+    const uint32_t w_s[2] = {lds_addr(Ws[0] + grp * 64 * LDK) + t_s, lds_addr(Ws[1] + grp * 64 * LDK) + t_s};
+
+    f32x4 ra[2][2], rw[2];      // this group's activation tile (128 x 32) and its half of the weight tile (64 x 32)
+    auto ld = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    auto load_a = [&](int kt) {
+        const int so = kt * (BK * 4);
+        ra[0][0] = ld(a_rsrc, t_g, so);
+        ra[0][1] = ld(a_rsrc, t_g + 16, so);
+        ra[1][0] = ld(a_rsrc, t_g, so + row64);
+        ra[1][1] = ld(a_rsrc, t_g + 16, so + row64);
+    };
+    auto load_w = [&](int kt) {
+        const int so = kt * (BK * 4);
+        rw[0] = ld(w_rsrc, t_g, so);
+        rw[1] = ld(w_rsrc, t_g + 16, so);
+    };
+    auto store_a = [&]() {
+        lds_store_deint8(a_s0, ra[0][0], ra[0][1]);
+        lds_store_deint8(a_s1, ra[1][0], ra[1][1]);
+    };
+    auto store_w = [&](int buf) { lds_store_deint8(w_s[buf], rw[0], rw[1]); };
+    auto lds_drain = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };   // the asm stores are invisible to the compiler's counters
+
+    // ---- prologue: W[0] (both halves) and A0[0] into LDS; group 1 leaves (A1[0], upper W[1]) in registers
+    load_w(0);
+    store_w(0);
+    load_a(0);
+    if (grp == 0) {
+        store_a();
+    } else if (nk > 1) {
+        load_w(1);
+    }
+    lds_drain();
+    __syncthreads();
+
+    const float *a_base = my_a + (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const int w_off = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
+
+    auto mfma_group = [&](const f32x4 (&af)[2], const f32x4 (&wf)[2]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], wf[j][q], acc[i][j], 0, 0, 0);
+    };
+
+    // one phase of K-tile u (PAR = u & 1 as a constant, HALF = which group computes)
+    auto phase = [&](auto par_c, auto half_c, int u) {
+        constexpr int PAR = decltype(par_c)::value, half = decltype(half_c)::value;
+        if (grp == half) {
+            LCREC_STAMP(0);
+            const float *w_base = Ws[PAR] + w_off;
+            f32x4 af[4][2], wf[4][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + g * 8);
+                    wf[g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + g * 8);
+                }
+            if (half == 0) {
+                if (u + 1 < nk) { load_a(u + 1); load_w(u + 1); }      // A0[u+1], lower W[u+1]
+            } else {
+                if (u + 1 < nk) load_a(u + 1);                          // A1[u+1]
+                if (u + 2 < nk) load_w(u + 2);                          // upper W[u+2]
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(af[0], wf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 2; g < 4; ++g)                                 // second half's fragments: in flight under 16 MFMAs
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + g * 8);
+                    wf[g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + g * 8);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(af[1], wf[1]);
+            __builtin_amdgcn_sched_barrier(0);                          // the barrier stays at MFMA 32 of 64
+            LCREC_STAMP(1);
+            __syncthreads();                                            // after this wave's LAST LDS read of the tile
+            LCREC_STAMP(2);
+            mfma_group(af[2], wf[2]);
+            mfma_group(af[3], wf[3]);
+            LCREC_STAMP(3);
+        } else {
+            LCREC_STAMP(0);
+            // half == 0: group 1 writes A1[u] and the upper half of W[u+1]; half == 1: group 0 writes A0[u+1] and
+            // the lower half of W[u+1] (registers of a tile past the end hold stale data nobody reads)
+            store_a();
+            store_w(PAR ^ 1);
+            lds_drain();
+            LCREC_STAMP(1);
+            __syncthreads();
+            LCREC_STAMP(2);
+        }
+    };
+
+    for (int u = 0; u < nk; u += 2) {
+        phase(IntC<0>{}, IntC<0>{}, u);
+        phase(IntC<0>{}, IntC<1>{}, u);
+        if (u + 1 < nk) {
+            phase(IntC<1>{}, IntC<0>{}, u + 1);
+            phase(IntC<1>{}, IntC<1>{}, u + 1);
+        }
+    }
+
+    float *stg = my_a + w4 * 32 * LDK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * 64 + i * 32, M, n0 + wn * 64 + j * 32, N, bias, bn_scale,
+                             bn_shift, relu);
+}
+
 static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *W, const float *b, const float *sc,
                             const float *sh, int relu, int out_dim, float *y, int tune, hipStream_t stream)
 {
@@ -485,13 +682,13 @@ static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *
     const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(K_LINEAR_PP, stream);
-    // every tile interior (rows % 256 == 0, columns % 128 == 0, K % 32 == 0): the guard-free instantiation
-    const bool full = n % 256 == 0 && out_dim % 128 == 0 && in_dim % BK == 0;
-    if (full)
-        hipLaunchKernelGGL(linear_fwd_pp_kernel<true>, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
-                           out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
+    // K % 32 == 0 (and a tile's operand rows addressable with 31 bits): the VALU-free form
+    static const int pp2 = [] { const char *e = getenv("LCREC_GEMM_PP2"); return e ? atoi(e) : 1; }();
+    if (pp2 && in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31))
+        hipLaunchKernelGGL(linear_fwd_pp2_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
+                           out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune & 1);
     else
-        hipLaunchKernelGGL(linear_fwd_pp_kernel<false>, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
+        hipLaunchKernelGGL(linear_fwd_pp_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
                            out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
     return check_launch("linear_fwd_pp_kernel");
 }
@@ -540,13 +737,7 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     // at Games size (66 row blocks) the finer-grained 128x128 kernel is 5-10 % faster
     const bool use_pp = out_dim > 64 && (pp == 1 || (pp == -1 && pp_tiles >= pp_min && n >= 256 * 256));
     if (use_pp) {
-        // whole 256-row panels go to the ping-pong kernel (guard-free when the widths divide too); the
-        // remaining < 256 rows are a second, small launch of the generic kernel -- same bits either way
-        const int64_t n_full = (out_dim % 128 == 0 && in_dim % BK == 0) ? n / 256 * 256 : n;
-        int rc = n_full ? launch_linear_pp(x, n_full, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream) : 0;
-        if (rc || n_full == n) return rc;
-        return launch_linear<2, 2, 1, 1>(x + n_full * in_dim, n - n_full, in_dim, W, b, bn_scale, bn_shift, relu, out_dim,
-                                         y + n_full * (int64_t)out_dim, stream);
+        return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
     }
     if (out_dim > 64) {
         // batch-sized problems (a training step has 1-2 k rows): 128 x 128 tiles would leave most CUs idle,
