@@ -42,6 +42,15 @@ namespace lcrec {
 // In-kernel cycle stamps (diagnostic builds only: make STAMP=1, then lcrec_debug_gemm_stamps()).
 #ifdef LCREC_GEMM_STAMP
 __device__ unsigned long long g_stamps[8][64][4];
+__device__ unsigned long long g_marks[8][4];      // kernel entry, prologue done, K loop done, epilogue done
+#define LCREC_MARK(slot)                                                                           \
+    do {                                                                                           \
+        if (blockIdx.x == 8 && lane == 0) {                                                        \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            g_marks[wave][slot] = t_;                                                              \
+        }                                                                                          \
+    } while (0)
 #define LCREC_STAMP(slot)                                                                          \
     do {                                                                                           \
         if (blockIdx.x == 8 && lane == 0 && 2 * u + half < 64) {                                   \
@@ -52,6 +61,7 @@ __device__ unsigned long long g_stamps[8][64][4];
     } while (0)
 #else
 #define LCREC_STAMP(slot) do { } while (0)
+#define LCREC_MARK(slot) do { } while (0)
 #endif
 
 constexpr int BK = 32;   // K slice per step
@@ -497,14 +507,24 @@ __device__ __forceinline__ void lds_store_deint8(uint32_t addr, const f32x4 &a, 
 template <int N>
 struct IntC { static constexpr int value = N; };
 
+// BKT = K slice per phase: 32 (64 MFMAs per wave and phase) or 64 (128 MFMAs).  The fixed costs of a phase --
+// the barrier (every wave waits for the slowest of the four computing waves, ~300 cycles of skew) and the hand-over
+// of the MFMA pipe between the two waves of a SIMD -- do not grow with the slice, so the longer phase halves
+// their share; 139 KB of the CU's 160 KB LDS hold the four operand buffers at BKT = 64.
+template <int BKT>
 __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
     int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int xcd_order)
 {
     constexpr int GM = 128, BN = 128;
-    __shared__ __attribute__((aligned(16))) float As[2][GM * LDK];
-    __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+    constexpr int LDT = BKT + 4;                 // padded LDS row (floats): 16 consecutive rows hit 16 distinct 16-B slots
+    constexpr int KG = BKT / 8;                  // 8-float groups per row = fragment groups per K slice
+    constexpr int RPI = 256 / KG;                // tile rows one pass of the group's 256 threads covers
+    constexpr int ITA = GM / RPI, ITW = 64 / RPI;
+    extern __shared__ __attribute__((aligned(16))) float pp2_lds[];
+    float *As0 = pp2_lds;                        // [2][GM * LDT]
+    float *Ws0 = pp2_lds + 2 * GM * LDT;         // [2][BN * LDT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -527,6 +547,7 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     const int n0 = bn * BN;
     const int64_t w_row0 = n0 + grp * 64;
 
+    LCREC_MARK(0);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -535,12 +556,12 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / BK;
-    float *my_a = As[grp];
+    const int nk = K / BKT;
+    float *my_a = As0 + grp * GM * LDT;
 
     // global side: one buffer descriptor per operand tile (stride 0 = raw; extent = the tile's valid rows, so
     // rows past the matrix read as 0.0f and an all-out-of-range tile touches no memory), a fixed per-thread
-    // byte offset (row gt/4, k-group gt%4), and the K-tile (and +64-row) byte offset in an SGPR
+    // byte offset (row gt/KG, k-group gt%KG), and the K-tile (and row-pass) byte offset in an SGPR
     auto tile_rsrc = [&](const float *base, int64_t first_row, int64_t total_rows, int tile_rows) {
         int64_t rows = total_rows - first_row;
         rows = rows < 0 ? 0 : (rows > tile_rows ? tile_rows : rows);
@@ -549,34 +570,46 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     };
     const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A, m0, M, GM);
     const __amdgpu_buffer_rsrc_t w_rsrc = tile_rsrc(W, w_row0, N, 64);
-    const int t_g = ((gt >> 2) * K + (gt & 3) * 8) * 4;
-    const int row64 = 64 * K * 4;
-    // LDS side: this thread's 8-float slot in row gt/4 (+64) of a tile
-    const uint32_t t_s = (uint32_t)(((gt >> 2) * LDK + (gt & 3) * 8) * 4);
-    const uint32_t a_s0 = lds_addr(my_a) + t_s, a_s1 = a_s0 + 64 * LDK * 4;
-    const uint32_t w_s[2] = {lds_addr(Ws[0] + grp * 64 * LDK) + t_s, lds_addr(Ws[1] + grp * 64 * LDK) + t_s};
+    const int t_g = ((gt / KG) * K + (gt % KG) * 8) * 4;
+    const int pass_g = RPI * K * 4;
+    // LDS side: this thread's 8-float slot in row gt/KG (+ RPI per pass) of a tile
+    const uint32_t t_s = (uint32_t)(((gt / KG) * LDT + (gt % KG) * 8) * 4);
+    uint32_t a_s[ITA], w_s[2][ITW];
+#pragma unroll
+    for (int it = 0; it < ITA; ++it) a_s[it] = lds_addr(my_a) + t_s + it * RPI * LDT * 4;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) w_s[b][it] = lds_addr(Ws0 + b * BN * LDT + grp * 64 * LDT) + t_s + it * RPI * LDT * 4;
 
-    f32x4 ra[2][2], rw[2];      // this group's activation tile (128 x 32) and its half of the weight tile (64 x 32)
+    f32x4 ra[ITA][2], rw[ITW][2];   // this group's activation tile (128 x BKT) and its half of the weight tile (64 x BKT)
     auto ld = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
     auto load_a = [&](int kt) {
-        const int so = kt * (BK * 4);
-        ra[0][0] = ld(a_rsrc, t_g, so);
-        ra[0][1] = ld(a_rsrc, t_g + 16, so);
-        ra[1][0] = ld(a_rsrc, t_g, so + row64);
-        ra[1][1] = ld(a_rsrc, t_g + 16, so + row64);
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            const int so = kt * (BKT * 4) + it * pass_g;
+            ra[it][0] = ld(a_rsrc, t_g, so);
+            ra[it][1] = ld(a_rsrc, t_g + 16, so);
+        }
     };
     auto load_w = [&](int kt) {
-        const int so = kt * (BK * 4);
-        rw[0] = ld(w_rsrc, t_g, so);
-        rw[1] = ld(w_rsrc, t_g + 16, so);
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            const int so = kt * (BKT * 4) + it * pass_g;
+            rw[it][0] = ld(w_rsrc, t_g, so);
+            rw[it][1] = ld(w_rsrc, t_g + 16, so);
+        }
     };
     auto store_a = [&]() {
-        lds_store_deint8(a_s0, ra[0][0], ra[0][1]);
-        lds_store_deint8(a_s1, ra[1][0], ra[1][1]);
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) lds_store_deint8(a_s[it], ra[it][0], ra[it][1]);
     };
-    auto store_w = [&](int buf) { lds_store_deint8(w_s[buf], rw[0], rw[1]); };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) lds_store_deint8(w_s[buf][it], rw[it][0], rw[it][1]);
+    };
     auto lds_drain = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };   // the asm stores are invisible to the compiler's counters
 
     // ---- prologue: W[0] (both halves) and A0[0] into LDS; group 1 leaves (A1[0], upper W[1]) in registers
@@ -590,9 +623,10 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     }
     lds_drain();
     __syncthreads();
+    LCREC_MARK(1);
 
-    const float *a_base = my_a + (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
-    const int w_off = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const float *a_base = my_a + (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int w_off = (wn * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
 
     auto mfma_group = [&](const f32x4 (&af)[2], const f32x4 (&wf)[2]) {
 #pragma unroll
@@ -604,44 +638,82 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], wf[j][q], acc[i][j], 0, 0, 0);
     };
 
-    // one phase of K-tile u (PAR = u & 1 as a constant, HALF = which group computes)
+    // one phase of K-tile u (PAR = u & 1 as a constant, half = which group computes)
     auto phase = [&](auto par_c, auto half_c, int u) {
         constexpr int PAR = decltype(par_c)::value, half = decltype(half_c)::value;
         if (grp == half) {
             LCREC_STAMP(0);
-            const float *w_base = Ws[PAR] + w_off;
-            f32x4 af[4][2], wf[4][2];
+            const float *w_base = Ws0 + PAR * BN * LDT + w_off;
+            // fragment registers: two buffers of two 8-wide groups each; a buffer is refilled as soon as its MFMAs have
+            // been issued, so its reads are in flight under the 16-32 MFMAs that follow
+            f32x4 af[2][2][2], wf[2][2][2];
+            auto frags = [&](int buf, int g0) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+                for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + g * 8);
-                    wf[g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + g * 8);
-                }
+                    for (int i = 0; i < 2; ++i) {
+                        af[buf][g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDT + (g0 + g) * 8);
+                        wf[buf][g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDT + (g0 + g) * 8);
+                    }
+            };
+            frags(0, 0);
             if (half == 0) {
                 if (u + 1 < nk) { load_a(u + 1); load_w(u + 1); }      // A0[u+1], lower W[u+1]
             } else {
                 if (u + 1 < nk) load_a(u + 1);                          // A1[u+1]
                 if (u + 2 < nk) load_w(u + 2);                          // upper W[u+2]
             }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_group(af[0], wf[0]);
-            __builtin_amdgcn_sched_barrier(0);
+            // LCREC_PP2_DEAL: deal a refill's 8 ds_read_b128 out one per MFMA instead of issuing them back to back
+            // (measured slower on MI355X, kept for experiments)
+            auto deal_reads = [&]() {
+#ifdef LCREC_PP2_DEAL
 #pragma unroll
-            for (int g = 2; g < 4; ++g)                                 // second half's fragments: in flight under 16 MFMAs
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + g * 8);
-                    wf[g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + g * 8);
+                for (int r = 0; r < 8; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
                 }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#else
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // the 8 reads first, then the MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+#endif
+            };
             __builtin_amdgcn_sched_barrier(0);
-            mfma_group(af[1], wf[1]);
-            __builtin_amdgcn_sched_barrier(0);                          // the barrier stays at MFMA 32 of 64
+            // (Measured and rejected: dealing the refill out one read per MFMA, and staggering it between the four
+            // waves -- both 5-7 % slower than one burst placed right after the 16th MFMA.)
+            mfma_group(af[0][0], wf[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            frags(1, 2);
+            mfma_group(af[0][1], wf[0][1]);
+            deal_reads();
+            if constexpr (KG == 8) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(af[1][0], wf[1][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                frags(0, 4);
+                mfma_group(af[1][1], wf[1][1]);
+                deal_reads();
+                __builtin_amdgcn_sched_barrier(0);
+                frags(1, 6);
+                mfma_group(af[0][0], wf[0][0]);
+                deal_reads();
+            }
+            __builtin_amdgcn_sched_barrier(0);                          // the barrier stays where it is written
             LCREC_STAMP(1);
             __syncthreads();                                            // after this wave's LAST LDS read of the tile
             LCREC_STAMP(2);
-            mfma_group(af[2], wf[2]);
-            mfma_group(af[3], wf[3]);
+            // From here on this wave's MFMAs outrank its partner's: the partner has just become the computing wave
+            // of the next phase and its first MFMAs are ready too, but every MFMA of theirs that overtakes one of
+            // these delays this wave's staging role, and the partner then waits for that staging at the next barrier
+            // (stamps: 330 cycles per phase).  With the order forced, staging finishes ~1 700 cycles before the
+            // partner reaches the barrier.
+            __builtin_amdgcn_s_setprio(3);
+            if constexpr (KG == 8) {
+                mfma_group(af[0][1], wf[0][1]);
+            }
+            mfma_group(af[1][0], wf[1][0]);
+            mfma_group(af[1][1], wf[1][1]);
+            __builtin_amdgcn_s_setprio(0);
             LCREC_STAMP(3);
         } else {
             LCREC_STAMP(0);
@@ -665,6 +737,8 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
         }
     }
 
+    LCREC_MARK(2);
+    // epilogue: each wave transposes through 32 x 36 floats of its OWN group's activation buffer
     float *stg = my_a + w4 * 32 * LDK;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -672,6 +746,24 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
         for (int i = 0; i < 2; ++i)
             store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * 64 + i * 32, M, n0 + wn * 64 + j * 32, N, bias, bn_scale,
                              bn_shift, relu);
+    LCREC_MARK(3);
+}
+
+template <int BKT>
+static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float *W, const float *b, const float *sc,
+                      const float *sh, float *y, int64_t n, int out_dim, int in_dim, int relu, int bn_blocks, int bm_blocks,
+                      int xcd_order)
+{
+    constexpr size_t lds = (size_t)(2 * 128 + 2 * 128) * (BKT + 4) * sizeof(float);
+    auto kern = linear_fwd_pp2_kernel<BKT>;
+    if (lds > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return fail(LCREC_EHIP, "linear_forward: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(attr));
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, bm_blocks,
+                       xcd_order);
+    return LCREC_OK;
 }
 
 static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *W, const float *b, const float *sc,
@@ -683,10 +775,17 @@ static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(K_LINEAR_PP, stream);
     // K % 32 == 0 (and a tile's operand rows addressable with 31 bits): the VALU-free form
+    // LCREC_GEMM_PP2: 0 = first form only, 64 = K slice of 64 where K allows (default: 32)
     static const int pp2 = [] { const char *e = getenv("LCREC_GEMM_PP2"); return e ? atoi(e) : 1; }();
-    if (pp2 && in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31))
-        hipLaunchKernelGGL(linear_fwd_pp2_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
-                           out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune & 1);
+    if (pp2 && in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31)) {
+        const bool wide = in_dim % 64 == 0 && pp2 == 64;    // measured: 32 is faster at every layer width (more phases, but
+                                                            // half the refill traffic per barrier interval)
+        int rc = wide ? launch_pp2<64>(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks,
+                                       (int)bm_blocks, tune & 1)
+                      : launch_pp2<32>(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks,
+                                       (int)bm_blocks, tune & 1);
+        if (rc) return rc;
+    }
     else
         hipLaunchKernelGGL(linear_fwd_pp_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
                            out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
@@ -756,5 +855,9 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
 extern "C" __attribute__((visibility("default"))) int lcrec_debug_gemm_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcrec::g_stamps), sizeof(unsigned long long) * 8 * 64 * 4);
+}
+extern "C" __attribute__((visibility("default"))) int lcrec_debug_gemm_marks(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcrec::g_marks), sizeof(unsigned long long) * 8 * 4);
 }
 #endif

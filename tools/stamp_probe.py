@@ -22,7 +22,7 @@ from lcrec_amd import _lib, ops  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1)
-    rows, k, n = 131072, 2048, 1024
+    rows, k, n = 131072, int(os.environ.get("PROBE_K", "2048")), int(os.environ.get("PROBE_N", "1024"))
     x = torch.randn((rows, k), generator=g, device=dev)
     w = torch.randn((n, k), generator=g, device=dev) * 0.02
     b = torch.zeros(n, device=dev)
@@ -53,8 +53,17 @@ def main():
     comp = np.array(comp)
     print("compute phase, mean cycles: entry->before barrier %.0f | in barrier %.0f | barrier->64th MFMA issued %.0f"
           % tuple(comp.mean(0)))
+    mbuf = (ctypes.c_ulonglong * (8 * 4))()
+    if hasattr(lib, "lcrec_debug_gemm_marks"):
+        lib.lcrec_debug_gemm_marks.argtypes = [ctypes.c_void_p]
+        assert lib.lcrec_debug_gemm_marks(ctypes.cast(mbuf, ctypes.c_void_p)) == 0
+        m = np.frombuffer(mbuf, dtype=np.uint64).reshape(8, 4).astype(np.int64)
+        for w in (0, 4):
+            d = np.diff(m[w])
+            print("wave %d of workgroup 8: prologue %d | K loop %d (%d K-tiles) | epilogue issued %d cycles"
+                  % (w, d[0], d[1], k // 32, d[2]))
     per = np.diff(s[0, 8:60:2, 0])
-    print("period of two phases (wave 0 entry to entry): mean %.0f cycles (ideal 8192)" % per.mean())
+    print("period of two phases (wave 0 entry to entry): mean %.0f cycles (ideal: 8192 at K slice 32, 16384 at 64)" % per.mean())
 
 
 if __name__ == "__main__":
