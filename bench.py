@@ -203,23 +203,30 @@ def main():
         elapsed = float(t.item())
 
     # Algorithmic flops per GEMM kernel: replay the library's dispatch rule (gemm_f32.hip, linear_forward)
-    # over the chunks lcrec_encode_assign walks (131072 rows each): wide layers go to the 256x128
-    # ping-pong kernel when the launch has >= 512 tiles and >= 65536 rows, else to the 128x128 kernel.
+    # over the chunks lcrec_encode_assign walks (131072 rows each).
+    def gemm_kernel_for(rows, out):
+        if out <= 32:
+            return "linear_fwd_128x32"
+        if out <= 64:
+            return "linear_fwd_128x64"
+        pp_tiles = -(-rows // 256) * -(-out // 128)
+        rounds = -(-pp_tiles // 256)
+        fits = pp_tiles >= 256 and (rounds >= 8 or pp_tiles * 5 >= rounds * 256 * 4)
+        forced = os.environ.get("LCREC_GEMM_PP", "-1")
+        if forced == "1" or (forced != "0" and fits):
+            return "linear_fwd_pp_256x128"
+        return "linear_fwd_64x64" if -(-rows // 128) * -(-out // 128) < 512 else "linear_fwd_128x128"
+
     macs_all = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1)) + sum(E_DIM * k for k in ks)
-    flops = {"linear_fwd_pp_256x128": 0.0, "linear_fwd_128x128": 0.0}
-    alg_bytes = {"linear_fwd_pp_256x128": 0.0, "linear_fwd_128x128": 0.0}
+    flops, alg_bytes = {}, {}
     for lo in range(0, n, 131072):
         rows = min(131072, n - lo)
         for l in range(len(dims) - 1):
             out = dims[l + 1]
-            if out <= 64:
-                continue
-            tiles = -(-rows // 256) * -(-out // 128)
-            pp = tiles >= 512 and rows >= 65536 and os.environ.get("LCREC_GEMM_PP", "-1") != "0"
-            kname = "linear_fwd_pp_256x128" if pp else "linear_fwd_128x128"
-            flops[kname] += 2.0 * rows * dims[l] * out * args.steps
+            kname = gemm_kernel_for(rows, out)
+            flops[kname] = flops.get(kname, 0.0) + 2.0 * rows * dims[l] * out * args.steps
             # read the activations and the weights once, write the outputs once
-            alg_bytes[kname] += 4.0 * (rows * dims[l] + out * dims[l] + rows * out) * args.steps
+            alg_bytes[kname] = alg_bytes.get(kname, 0.0) + 4.0 * (rows * dims[l] + out * dims[l] + rows * out) * args.steps
     dom = max(flops, key=lambda k: flops[k])
     launches, total_ms = trace.get(dom, (0, 0.0))
     flops_dom_total = flops[dom]

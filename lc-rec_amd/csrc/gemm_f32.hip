@@ -507,17 +507,18 @@ __device__ __forceinline__ void lds_store_deint8(uint32_t addr, const f32x4 &a, 
 template <int N>
 struct IntC { static constexpr int value = N; };
 
-// BKT = K slice per phase: 32 (64 MFMAs per wave and phase) or 64 (128 MFMAs).  The fixed costs of a phase --
-// the barrier (every wave waits for the slowest of the four computing waves, ~300 cycles of skew) and the hand-over
-// of the MFMA pipe between the two waves of a SIMD -- do not grow with the slice, so the longer phase halves
-// their share; 139 KB of the CU's 160 KB LDS hold the four operand buffers at BKT = 64.
-template <int BKT>
+// Measured and rejected on MI355X (tools/gemm_probe.py, TFLOP/s on the 768->2048 / 2048->1024 layers; this form: 141 / 151):
+//   K slice of 64 per phase (half the barriers, 139 KB of LDS)                       133 / 144
+//   two workgroups per CU (register-capped to 128 VGPRs, 2 x 74 KB LDS)               137 / 140
+//   fragment refills dealt out one ds_read per MFMA, or staggered between the waves   123-132 / 129-140
+// What is left is per-tile: ~3.5 k cycles of prologue and ~10 k of epilogue (all 256 CUs store their 128 KB
+// tiles at the same moment) against 8 225 cycles per K-tile in the loop (ideal 8 192).
 __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
     int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int xcd_order)
 {
-    constexpr int GM = 128, BN = 128;
+    constexpr int GM = 128, BN = 128, BKT = BK;
     constexpr int LDT = BKT + 4;                 // padded LDS row (floats): 16 consecutive rows hit 16 distinct 16-B slots
     constexpr int KG = BKT / 8;                  // 8-float groups per row = fragment groups per K slice
     constexpr int RPI = 256 / KG;                // tile rows one pass of the group's 256 threads covers
@@ -639,80 +640,56 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     };
 
     // one phase of K-tile u (PAR = u & 1 as a constant, half = which group computes)
+    // one phase of K-tile u (PAR = u & 1 as a constant, half = which group computes)
     auto phase = [&](auto par_c, auto half_c, int u) {
         constexpr int PAR = decltype(par_c)::value, half = decltype(half_c)::value;
         if (grp == half) {
             LCREC_STAMP(0);
             const float *w_base = Ws0 + PAR * BN * LDT + w_off;
-            // fragment registers: two buffers of two 8-wide groups each; a buffer is refilled as soon as its MFMAs have
-            // been issued, so its reads are in flight under the 16-32 MFMAs that follow
-            f32x4 af[2][2][2], wf[2][2][2];
-            auto frags = [&](int buf, int g0) {
+            // fragment registers: one 16-VGPR buffer per 8-wide k group; a buffer is refilled as soon as the MFMAs that
+            // read it have been issued, so the refill is in flight under the 16 MFMAs that follow.  (Measured and
+            // rejected: dealing a refill out one read per MFMA, and staggering it between the four waves -- both
+            // 5-7 % slower than one burst.)
+            f32x4 af[2][2], wf[2][2];
+            auto frags = [&](int buf, int g) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        af[buf][g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDT + (g0 + g) * 8);
-                        wf[buf][g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDT + (g0 + g) * 8);
-                    }
+                for (int i = 0; i < 2; ++i) {
+                    af[buf][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDT + g * 8);
+                    wf[buf][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDT + g * 8);
+                }
+            };
+            auto reads_then_mfmas = [&]() {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             };
             frags(0, 0);
+            frags(1, 1);
             if (half == 0) {
                 if (u + 1 < nk) { load_a(u + 1); load_w(u + 1); }      // A0[u+1], lower W[u+1]
             } else {
                 if (u + 1 < nk) load_a(u + 1);                          // A1[u+1]
                 if (u + 2 < nk) load_w(u + 2);                          // upper W[u+2]
             }
-            // LCREC_PP2_DEAL: deal a refill's 8 ds_read_b128 out one per MFMA instead of issuing them back to back
-            // (measured slower on MI355X, kept for experiments)
-            auto deal_reads = [&]() {
-#ifdef LCREC_PP2_DEAL
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#else
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // the 8 reads first, then the MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-#endif
-            };
             __builtin_amdgcn_sched_barrier(0);
-            // (Measured and rejected: dealing the refill out one read per MFMA, and staggering it between the four
-            // waves -- both 5-7 % slower than one burst placed right after the 16th MFMA.)
-            mfma_group(af[0][0], wf[0][0]);
+            mfma_group(af[0], wf[0]);                                   // k group 0
             __builtin_amdgcn_sched_barrier(0);
-            frags(1, 2);
-            mfma_group(af[0][1], wf[0][1]);
-            deal_reads();
-            if constexpr (KG == 8) {
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_group(af[1][0], wf[1][0]);
-                __builtin_amdgcn_sched_barrier(0);
-                frags(0, 4);
-                mfma_group(af[1][1], wf[1][1]);
-                deal_reads();
-                __builtin_amdgcn_sched_barrier(0);
-                frags(1, 6);
-                mfma_group(af[0][0], wf[0][0]);
-                deal_reads();
-            }
+            frags(0, 2);
+            mfma_group(af[1], wf[1]);                                   // k group 1
+            reads_then_mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            frags(1, 3);
+            mfma_group(af[0], wf[0]);                                   // k group 2
+            reads_then_mfmas();
             __builtin_amdgcn_sched_barrier(0);                          // the barrier stays where it is written
             LCREC_STAMP(1);
             __syncthreads();                                            // after this wave's LAST LDS read of the tile
             LCREC_STAMP(2);
             // From here on this wave's MFMAs outrank its partner's: the partner has just become the computing wave
             // of the next phase and its first MFMAs are ready too, but every MFMA of theirs that overtakes one of
-            // these delays this wave's staging role, and the partner then waits for that staging at the next barrier
-            // (stamps: 330 cycles per phase).  With the order forced, staging finishes ~1 700 cycles before the
-            // partner reaches the barrier.
+            // these delays this wave's staging role, and the partner would then wait for that staging at the next
+            // barrier (stamps: 330 cycles per phase).
             __builtin_amdgcn_s_setprio(3);
-            if constexpr (KG == 8) {
-                mfma_group(af[0][1], wf[0][1]);
-            }
-            mfma_group(af[1][0], wf[1][0]);
-            mfma_group(af[1][1], wf[1][1]);
+            mfma_group(af[1], wf[1]);                                   // k group 3
             __builtin_amdgcn_s_setprio(0);
             LCREC_STAMP(3);
         } else {
@@ -749,20 +726,16 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     LCREC_MARK(3);
 }
 
-template <int BKT>
 static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float *W, const float *b, const float *sc,
                       const float *sh, float *y, int64_t n, int out_dim, int in_dim, int relu, int bn_blocks, int bm_blocks,
                       int xcd_order)
 {
-    constexpr size_t lds = (size_t)(2 * 128 + 2 * 128) * (BKT + 4) * sizeof(float);
-    auto kern = linear_fwd_pp2_kernel<BKT>;
-    if (lds > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return fail(LCREC_EHIP, "linear_forward: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(attr));
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, bm_blocks,
-                       xcd_order);
+    constexpr size_t lds = (size_t)(2 * 128 + 2 * 128) * (BK + 4) * sizeof(float);     // 73 728 B
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_fwd_pp2_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return fail(LCREC_EHIP, "linear_forward: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(attr));
+    hipLaunchKernelGGL(linear_fwd_pp2_kernel, grid, dim3(512), lds, stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu,
+                       bn_blocks, bm_blocks, xcd_order);
     return LCREC_OK;
 }
 
@@ -775,15 +748,10 @@ static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(K_LINEAR_PP, stream);
     // K % 32 == 0 (and a tile's operand rows addressable with 31 bits): the VALU-free form
-    // LCREC_GEMM_PP2: 0 = first form only, 64 = K slice of 64 where K allows (default: 32)
-    static const int pp2 = [] { const char *e = getenv("LCREC_GEMM_PP2"); return e ? atoi(e) : 1; }();
+    static const int pp2 = [] { const char *e = getenv("LCREC_GEMM_PP2"); return e ? atoi(e) : 1; }();   // 0: first form only
     if (pp2 && in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31)) {
-        const bool wide = in_dim % 64 == 0 && pp2 == 64;    // measured: 32 is faster at every layer width (more phases, but
-                                                            // half the refill traffic per barrier interval)
-        int rc = wide ? launch_pp2<64>(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks,
-                                       (int)bm_blocks, tune & 1)
-                      : launch_pp2<32>(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks,
-                                       (int)bm_blocks, tune & 1);
+        int rc = launch_pp2(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks,
+                            (int)bm_blocks, tune & 1);
         if (rc) return rc;
     }
     else
@@ -825,16 +793,17 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     if (((uintptr_t)x | (uintptr_t)W) & 15)
         return fail(LCREC_EINVAL, "linear_forward: x and W must be 16-byte aligned");
     if (n == 0) return LCREC_OK;
-    // Wide layers: the ping-pong kernel (one 512-thread workgroup per CU) wins once there are enough
-    // 256 x 128 tiles to keep every CU busy for several rounds; small problems keep the 128 x 128 kernel
-    // (three workgroups per CU, finer tail).  LCREC_GEMM_PP=0/1 forces one or the other (tuning only).
+    // Wide layers: the ping-pong kernel (one 512-thread workgroup per CU) wins as soon as its 256 x 128 tiles fill
+    // the 256 CUs in whole rounds: at least one round, and either >= 8 rounds or <= 20 % of the last round empty
+    // (measured with tools/pp_sweep.sh: 8 192 x 768->2048 = 512 tiles: 117 vs 89 TFLOP/s; 16 896 x 1024->512 = 264
+    // tiles: 76 vs 83).  Otherwise the 128 x 128 / 64 x 64 kernels (several workgroups per CU, finer tail).
+    // LCREC_GEMM_PP=0/1 forces one or the other (tuning only).
     static const int pp = [] { const char *e = getenv("LCREC_GEMM_PP"); return e ? atoi(e) : -1; }();
     static const int pp_tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & LCREC_TUNE_MASK; }();
     const int64_t pp_tiles = ((n + 255) / 256) * ((out_dim + 127) / 128);
-    static const int pp_min = [] { const char *e = getenv("LCREC_GEMM_PP_MIN_TILES"); return e ? atoi(e) : 512; }();
-    // measured on MI355X: with >= 256 row blocks the ping-pong kernel wins at every width (C3/C4 chunks);
-    // at Games size (66 row blocks) the finer-grained 128x128 kernel is 5-10 % faster
-    const bool use_pp = out_dim > 64 && (pp == 1 || (pp == -1 && pp_tiles >= pp_min && n >= 256 * 256));
+    const int64_t pp_rounds = (pp_tiles + 255) / 256;
+    const bool pp_fits = pp_tiles >= 256 && (pp_rounds >= 8 || pp_tiles * 5 >= pp_rounds * 256 * 4);
+    const bool use_pp = out_dim > 64 && (pp == 1 || (pp == -1 && pp_fits));
     if (use_pp) {
         return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
     }
