@@ -555,17 +555,33 @@ static inline int sk_class(int64_t sz, int K)
     return sz <= SKS_SLAB_MAX_ROWS ? 2 : 3;
 }
 
-struct SkPlan { int64_t slab_doubles; int64_t biggest; int n_slab; };
+// slab_ok: whether the mid-sized groups (class 2) of this call run side by side, one workgroup each, or one after
+// another as batch-sized problems.  One workgroup walks its g x K matrix ~5 times per iteration out of L2: about
+// 5 us per row at K = 256 for 50 iterations; a batch-sized solve costs ~0.7 ms whatever its size.  A training
+// step's single 2048-row group must take the batch path (0.8 ms, not 10); a collision round's hundred groups of
+// 65..3000 rows must not (15 ms side by side, not 80 ms in a row).
+struct SkPlan { int64_t slab_doubles; int64_t biggest; int n_slab; bool slab_ok; };
 
 static SkPlan sk_plan(int K, const int64_t *offs, int G)
 {
-    SkPlan p = {0, 0, 0};
+    SkPlan p = {0, 0, 0, false};
+    int64_t mid_max = 0, mid_biggest = 0;
+    int n_mid = 0;
     for (int g = 0; g < G; ++g) {
         const int64_t sz = offs[g + 1] - offs[g];
         if (sz <= 0) continue;
         const int cls = sk_class(sz, K);
-        if (cls == 2) { p.slab_doubles += (int64_t)sk_group_doubles(sz, K); ++p.n_slab; }
+        if (cls == 2) { p.slab_doubles += (int64_t)sk_group_doubles(sz, K); ++n_mid; if (sz > mid_max) mid_max = sz; }
+        if (cls >= 2 && sz > mid_biggest) mid_biggest = sz;
         if (cls == 3 && sz > p.biggest) p.biggest = sz;
+    }
+    const double side_by_side_us = (double)mid_max * 5.0 * (K / 256.0) * ((n_mid + 255) / 256);
+    p.slab_ok = n_mid > 0 && side_by_side_us <= 700.0 * n_mid;
+    if (p.slab_ok) {
+        p.n_slab = n_mid;
+    } else {
+        p.slab_doubles = 0;
+        p.biggest = mid_biggest;            // the mid-sized groups go through the batch path too
     }
     return p;
 }
@@ -890,7 +906,7 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
         int64_t slab = 0;
         for (int g = 0; g < G; ++g) {
             const int64_t sz = offs[g + 1] - offs[g];
-            if (sz <= 0 || sk_class(sz, K) != cls) continue;
+            if (sz <= 0 || sk_class(sz, K) != cls || (cls == 2 && !plan.slab_ok)) continue;
             triples.push_back(offs[g]);
             triples.push_back(offs[g + 1]);
             triples.push_back(cls == 2 ? slab : 0);
@@ -915,7 +931,8 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
     // larger problems (a training batch) go through the multi-launch path, one at a time
     for (int g = 0; g < G; ++g) {
         const int64_t sz = offs[g + 1] - offs[g];
-        if (sz > 0 && sk_class(sz, K) == 3) {
+        const int cls = sz > 0 ? sk_class(sz, K) : -1;
+        if (cls == 3 || (cls == 2 && !plan.slab_ok)) {
             int rc = sinkhorn_big(r + offs[g] * e, sz, e, cb, K, eps, iters, idx_out + offs[g] * idx_stride, idx_stride, ws, stream);
             if (rc) return rc;
         }

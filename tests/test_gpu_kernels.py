@@ -19,6 +19,11 @@ def _rs(seed):
     (4096, 2048, 1024, True, True),
     (77, 4096, 2048, True, False),
     (1, 8, 32, False, False),
+    # launches that fill the CUs in whole rounds of 256 x 128 tiles go to the ping-pong kernels:
+    (8192, 64, 2048, True, True),        # second form (K % 32 == 0), every tile interior
+    (16000, 32, 2000, True, False),      # second form, ragged: last row panel half empty, last column tile partial
+    (8192, 72, 2048, True, False),       # first form (K % 32 != 0)
+    (8192, 40, 2001, False, True),       # first form, odd width (scalar stores)
 ])
 def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     rs = _rs(n + k + out)
@@ -30,9 +35,13 @@ def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     want = oracle.linear(x, W, b, sc, sh, relu=relu, threads=8)
     dev = torch.device("cuda:0")
     t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    hip.ops.trace_enable(True)
     got = hip.ops.linear_forward(t(x), t(W), t(b), t(sc), t(sh), relu=relu).cpu().numpy()
+    trace = hip.ops.trace_collect()
+    hip.ops.trace_enable(False)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+    assert ("linear_fwd_pp_256x128" in trace) == (n >= 8192), trace      # the intended kernel ran
 
 
 @pytest.mark.parametrize("n,e,Ks", [
@@ -137,11 +146,18 @@ def test_sinkhorn_training_batch(hip, B, K, e):
     cb = (0.8 * rs.standard_normal((K, e))).astype(np.float32)
     want, margin = _ref_sinkhorn_idx(z, cb, 0.003, 50)
     dev = torch.device("cuda:0")
+    hip.ops.trace_enable(True)
     got = hip.ops.sinkhorn_assign(torch.from_numpy(z).to(dev), torch.from_numpy(cb).to(dev), 0.003, 50).cpu().numpy()
+    trace = hip.ops.trace_collect()
+    hip.ops.trace_enable(False)
     bad = got != want
     # fp64 exp/sum order differs from torch CPU by ulps: only rows whose top-2 margin is at that level may move
     assert not (bad & (margin > 1e-9)).any(), f"{bad.sum()} rows differ, min margin of those {margin[bad].min()}"
     assert bad.mean() < 1e-3
+    if B >= 1000:
+        # a lone batch-sized problem must take the multi-workgroup solver, not the one-workgroup-per-group
+        # kernel of the collision rounds (that is 10 ms instead of 0.8 ms per training step)
+        assert "sinkhorn" in trace and "sinkhorn_small" not in trace, trace
 
 
 def test_sinkhorn_golden_fixture(hip):
