@@ -24,6 +24,9 @@ def _rs(seed):
     (16000, 32, 2000, True, False),      # second form, ragged: last row panel half empty, last column tile partial
     (8192, 72, 2048, True, False),       # first form (K % 32 != 0)
     (8192, 40, 2001, False, True),       # first form, odd width (scalar stores)
+    (8192, 256, 2048, True, True),       # persistent form when enabled: two tiles per workgroup, BatchNorm epilogue
+    (16000, 192, 2048, True, False),     # ... four tiles per workgroup, last row panel half empty
+    (8200, 384, 4096, False, False),     # ... 33 row panels over 8 XCDs (holes in the tile walk), no ReLU
 ])
 def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     rs = _rs(n + k + out)
