@@ -64,8 +64,6 @@ __device__ unsigned long long g_marks[8][4];      // kernel entry, prologue done
 #define LCREC_MARK(slot) do { } while (0)
 #endif
 
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
 constexpr int BK = 32;   // K slice per step
 constexpr int LDK = 36;  // padded LDS row length in floats
 
@@ -566,6 +564,10 @@ struct IntC { static constexpr int value = N; };
 //   K slice of 64 per phase (half the barriers, 139 KB of LDS)                       133 / 144
 //   two workgroups per CU (register-capped to 128 VGPRs, 2 x 74 KB LDS)               137 / 140
 //   fragment refills dealt out one ds_read per MFMA, or staggered between the waves   123-132 / 129-140
+//   persistent workgroups (one per CU walking 16-32 tiles, K-tile stream flat across tiles, second accumulator
+//   set so that bias/BN/ReLU and the stores of tile t run under tile t+1): bit-exact, but      133 / 141
+//   (the K loop itself got 8 % slower -- 252 VGPRs, static tile assignment -- and ate the saved prologue/epilogue;
+//   the code is in the repository history: "Experiment: persistent ping-pong GEMM ...")
 // What is left is per-tile: ~3.5 k cycles of prologue and ~10 k of epilogue (all 256 CUs store their 128 KB
 // tiles at the same moment) against 8 225 cycles per K-tile in the loop (ideal 8 192).
 __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
@@ -772,291 +774,6 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     LCREC_MARK(3);
 }
 
-// ------------------------------------------------------------------------------------------
-// Ping-pong kernel, persistent form (K % 64 == 0, K >= 192, N % 128 == 0): one workgroup per CU walks a
-// sequence of output tiles and never drains its pipeline between them.
-//   * The K-tile stream is flat across tiles: the prefetch of "K-tile nk" is simply K-tile 0 of the next
-//     tile (other buffer descriptors), so there is no prologue after the first tile and no workgroup
-//     turn-around.
-//   * Two accumulator sets alternate between tiles.  A finished set is post-processed while the next tile
-//     accumulates into the other: bias / BatchNorm / ReLU in the wave's next COMPUTE phase (its own VALU
-//     work issues in the shadow of its own MFMAs), then one 32 x 32 sub-tile per STAGING phase goes through a
-//     wave-private LDS patch to 16-byte buffer stores (LDS and vector-memory ports only; rows past M are
-//     dropped by the descriptor's range check).  The 128 KB per CU that linear_fwd_pp2_kernel stores in one
-//     burst at the end of every tile -- all 256 CUs at the same instant -- now drains under four K-tiles.
-// Same arithmetic as every other kernel here: one fma chain per output over k ascending, epilogue after it.
-// ------------------------------------------------------------------------------------------
-
-template <bool HAS_BN>
-__global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
-    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
-    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int total_virtual, int xcd_order, int sync_epilogue)
-{
-    constexpr int GM = 128, BN = 128, LDT = LDK;
-    extern __shared__ __attribute__((aligned(16))) float pp3_lds[];
-    float *As0 = pp3_lds;                        // [2][GM * LDT]
-    float *Ws0 = As0 + 2 * GM * LDT;             // [2][BN * LDT]
-    float *Ep0 = Ws0 + 2 * BN * LDT;             // [8][32 * LDT] wave-private transpose patches
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
-    const int gt = tid & 255;
-    const int nk = K / BK;
-    float *my_a = As0 + grp * GM * LDT;
-    float *patch = Ep0 + wave * 32 * LDT;
-
-    // tile walker: (m0 = first row of this GROUP's 128-row half, n0 = first column) as plain scalars -- they have to
-    // stay in SGPRs for the buffer descriptors built from them
-    // (row counts are clamped here, once per tile: 64-bit compares have no scalar form and would otherwise sit on
-    // the VALU port in every phase)
-    auto tile_of = [&](int t, int64_t &o_m0, int &o_n0, int &o_arows, int &o_wrows) __attribute__((always_inline)) -> bool {
-        int64_t bm;
-        int bn;
-        if (xcd_order) {
-            const int xcd = t & 7, j = t >> 3;
-            const int panels = (bm_blocks - xcd + 7) >> 3;
-            if (j >= panels * bn_blocks) return false;
-            bm = (int64_t)(j / bn_blocks) * 8 + xcd;
-            bn = j % bn_blocks;
-        } else {
-            if (t >= bm_blocks * bn_blocks) return false;
-            bm = t / bn_blocks;
-            bn = t % bn_blocks;
-        }
-        o_m0 = bm * (2 * GM) + grp * GM;
-        o_n0 = bn * BN;
-        const int64_t ar = M - o_m0, wr = (int64_t)N - (o_n0 + grp * 64);
-        o_arows = __builtin_amdgcn_readfirstlane((int)(ar < 0 ? 0 : (ar > GM ? GM : ar)));
-        o_wrows = __builtin_amdgcn_readfirstlane((int)(wr < 0 ? 0 : (wr > 64 ? 64 : wr)));
-        return true;
-    };
-    auto next_tile = [&](int t, int64_t &o_m0, int &o_n0, int &o_arows, int &o_wrows) __attribute__((always_inline)) -> int {
-        for (t += gridDim.x; t < total_virtual; t += gridDim.x)
-            if (tile_of(t, o_m0, o_n0, o_arows, o_wrows)) return t;
-        return total_virtual;
-    };
-
-    int64_t cur_m0 = 0, nxt_m0 = 0, prv_m0 = 0;
-    int cur_n0 = 0, nxt_n0 = 0, prv_n0 = 0, cur_ar = 0, nxt_ar = 0, prv_ar = 0, cur_wr = 0, nxt_wr = 0;
-    int t = blockIdx.x;
-    if (!tile_of(t, cur_m0, cur_n0, cur_ar, cur_wr)) t = next_tile(t, cur_m0, cur_n0, cur_ar, cur_wr);
-    if (t >= total_virtual) return;
-    int has_next = 0, have_prev = 0;        // ints, not bools: a uniform i1 that lives across blocks is lowered through VGPRs
-
-    const int t_g = ((gt >> 2) * K + (gt & 3) * 8) * 4;
-    const int pass_g = 64 * K * 4;
-    const uint32_t t_s = (uint32_t)(((gt >> 2) * LDT + (gt & 3) * 8) * 4);
-    const uint32_t a_s0 = lds_addr(my_a) + t_s, a_s1 = a_s0 + 64 * LDT * 4;
-    const uint32_t w_s[2] = {lds_addr(Ws0 + grp * 64 * LDT) + t_s, lds_addr(Ws0 + BN * LDT + grp * 64 * LDT) + t_s};
-
-    f32x4 ra[2][2], rw[2];
-    // K-tile kt of the current tile, or K-tile kt - nk of the next one (nothing past the last tile)
-    auto load_a = [&](int kt) __attribute__((always_inline)) {
-        if (kt >= nk && has_next == 0) return;
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(A + (kt < nk ? cur_m0 : nxt_m0) * (int64_t)K), 0, (kt < nk ? cur_ar : nxt_ar) * K * 4, 0x00020000);
-        const int so = (kt < nk ? kt : kt - nk) * (BK * 4);
-        ra[0][0] = buffer_load_f32x4(r, t_g, so);
-        ra[0][1] = buffer_load_f32x4(r, t_g + 16, so);
-        ra[1][0] = buffer_load_f32x4(r, t_g, so + pass_g);
-        ra[1][1] = buffer_load_f32x4(r, t_g + 16, so + pass_g);
-    };
-    auto load_w = [&](int kt) __attribute__((always_inline)) {
-        if (kt >= nk && has_next == 0) return;
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(W + (int64_t)((kt < nk ? cur_n0 : nxt_n0) + grp * 64) * K), 0, (kt < nk ? cur_wr : nxt_wr) * K * 4,
-            0x00020000);
-        const int so = (kt < nk ? kt : kt - nk) * (BK * 4);
-        rw[0] = buffer_load_f32x4(r, t_g, so);
-        rw[1] = buffer_load_f32x4(r, t_g + 16, so);
-    };
-    auto store_a = [&]() {
-        lds_store_deint8(a_s0, ra[0][0], ra[0][1]);
-        lds_store_deint8(a_s1, ra[1][0], ra[1][1]);
-    };
-    auto store_w = [&](int buf) { lds_store_deint8(w_s[buf], rw[0], rw[1]); };
-    auto lds_drain = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-
-    // per-column epilogue constants of a tile: this lane's two columns (j = 0, 1)
-    struct EpiConst { float b[2], sc[2], sh[2]; };
-    auto load_epi = [&](EpiConst &e, int n0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            e.b[j] = bias ? bias[col] : 0.f;
-            e.sc[j] = HAS_BN ? bn_scale[col] : 1.f;
-            e.sh[j] = HAS_BN ? bn_shift[col] : 0.f;
-        }
-    };
-    // bias / BatchNorm / ReLU in place on a finished accumulator set
-    auto epi_math = [&](f32x16 (&p)[2][2], const EpiConst &e) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = p[i][j][r] + e.b[j];
-                    if (HAS_BN) v = __builtin_fmaf(v, e.sc[j], e.sh[j]);
-                    if (relu) v = (v > 0.f) ? v : 0.f;
-                    p[i][j][r] = v;
-                }
-    };
-    // one 32 x 32 sub-tile of a post-processed accumulator set -> C, through this wave's LDS patch
-    auto epi_store = [&](const f32x16 &v, int i, int j, int64_t t_m0, int t_n0, int rows) __attribute__((always_inline)) {
-        const int extent = rows > 0 ? ((rows - 1) * N + BN) * 4 : 0;
-        const __amdgpu_buffer_rsrc_t c_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(C + t_m0 * (int64_t)N + t_n0, 0, extent, 0x00020000);
-        const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * LDT + c] = v[r];
-        __builtin_amdgcn_wave_barrier();
-        const int voff = ((lane >> 3) * N + (lane & 7) * 4) * 4;
-#pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) {
-            const f32x4 q = *reinterpret_cast<const f32x4 *>(patch + ((lane >> 3) + 8 * p4) * LDT + (lane & 7) * 4);
-            const int soff = ((wm * 64 + i * 32 + 8 * p4) * N + wn * 64 + j * 32) * 4;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, q), c_rsrc, voff, soff, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    // ---- prologue of the first tile: W[0] (both halves) and A0[0] into LDS; group 1 keeps (A1[0], upper W[1])
-    load_w(0);
-    store_w(0);
-    load_a(0);
-    if (grp == 0) {
-        store_a();
-    } else {
-        load_w(1);
-    }
-    lds_drain();
-    __syncthreads();
-
-    const float *a_base = my_a + (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
-    const int w_off = (wn * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
-
-    // one phase of K-tile u of the current tile: acc accumulates it; prev is the finished set of the previous tile
-    auto phase = [&](auto par_c, auto half_c, int u, f32x16 (&acc)[2][2], f32x16 (&prev)[2][2], EpiConst &ecur,
-                     const EpiConst &eprev) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_c)::value, half = decltype(half_c)::value;
-        if (grp == half) {
-            const float *w_base = Ws0 + PAR * BN * LDT + w_off;
-            f32x4 af[2][2], wf[2][2];
-            auto frags = [&](int buf, int g) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[buf][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDT + g * 8);
-                    wf[buf][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDT + g * 8);
-                }
-            };
-            auto mfma_group = [&](const f32x4 (&a2)[2], const f32x4 (&w2)[2]) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i][q], w2[j][q], acc[i][j], 0, 0, 0);
-            };
-            auto reads_then_mfmas = [&]() {
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-            };
-            if (PAR == 0 && u == 0) {
-                // first K-tile of a tile: this tile's epilogue constants, a zeroed accumulator set, and the
-                // previous tile's post-processing
-                load_epi(ecur, cur_n0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                if (have_prev) epi_math(prev, eprev);
-            }
-            frags(0, 0);
-            frags(1, 1);
-            __builtin_amdgcn_sched_barrier(0);                          // fragment reads first: the MFMAs wait for them
-            if (half == 0) {
-                load_a(u + 1);                                          // A0[u+1], lower W[u+1]
-                load_w(u + 1);
-            } else {
-                load_a(u + 1);                                          // A1[u+1]
-                load_w(u + 2);                                          // upper W[u+2]
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_group(af[0], wf[0]);                                   // k group 0
-            __builtin_amdgcn_sched_barrier(0);
-            frags(0, 2);
-            mfma_group(af[1], wf[1]);                                   // k group 1
-            reads_then_mfmas();
-            __builtin_amdgcn_sched_barrier(0);
-            frags(1, 3);
-            mfma_group(af[0], wf[0]);                                   // k group 2
-            reads_then_mfmas();
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                                            // after this wave's LAST LDS read of the tile
-            __builtin_amdgcn_s_setprio(3);
-            mfma_group(af[1], wf[1]);                                   // k group 3
-            __builtin_amdgcn_s_setprio(0);
-        } else {
-            store_a();
-            store_w(PAR ^ 1);
-            lds_drain();
-            // K-tiles 1..4 of a tile: one sub-tile of the previous tile's output per staging phase
-            if (have_prev) {
-                const int a = u >> 1;
-                if (PAR == 1) {
-                    if (a == 0) epi_store(prev[0][0], 0, 0, prv_m0, prv_n0, prv_ar);
-                    else if (a == 1) epi_store(prev[1][0], 1, 0, prv_m0, prv_n0, prv_ar);
-                } else {
-                    if (a == 1) epi_store(prev[0][1], 0, 1, prv_m0, prv_n0, prv_ar);
-                    else if (a == 2) epi_store(prev[1][1], 1, 1, prv_m0, prv_n0, prv_ar);
-                }
-            }
-            __syncthreads();
-        }
-    };
-
-    f32x16 accA[2][2], accB[2][2];
-    EpiConst eA, eB;
-    auto run_tile = [&](f32x16 (&acc)[2][2], f32x16 (&prev)[2][2], EpiConst &ecur, const EpiConst &eprev) __attribute__((always_inline)) {
-        for (int u = 0; u < nk; u += 2) {
-            phase(IntC<0>{}, IntC<0>{}, u, acc, prev, ecur, eprev);
-            phase(IntC<0>{}, IntC<1>{}, u, acc, prev, ecur, eprev);
-            phase(IntC<1>{}, IntC<0>{}, u + 1, acc, prev, ecur, eprev);
-            phase(IntC<1>{}, IntC<1>{}, u + 1, acc, prev, ecur, eprev);
-        }
-    };
-    auto finish = [&](f32x16 (&acc)[2][2], const EpiConst &e) __attribute__((always_inline)) {     // the block's last tile: nothing left to hide behind
-        epi_math(acc, e);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) epi_store(acc[i][j], i, j, cur_m0, cur_n0, cur_ar);
-    };
-
-    for (;;) {
-        int tn = next_tile(t, nxt_m0, nxt_n0, nxt_ar, nxt_wr);
-        has_next = tn < total_virtual ? 1 : 0;
-        run_tile(accA, accB, eA, eB);
-        if (!has_next || sync_epilogue) finish(accA, eA);
-        if (!has_next) break;
-        prv_m0 = cur_m0; prv_n0 = cur_n0; prv_ar = cur_ar;
-        cur_m0 = nxt_m0; cur_n0 = nxt_n0; cur_ar = nxt_ar; cur_wr = nxt_wr; t = tn; have_prev = sync_epilogue ? 0 : 1;
-        tn = next_tile(t, nxt_m0, nxt_n0, nxt_ar, nxt_wr);
-        has_next = tn < total_virtual ? 1 : 0;
-        run_tile(accB, accA, eB, eA);
-        if (!has_next || sync_epilogue) finish(accB, eB);
-        if (!has_next) break;
-        prv_m0 = cur_m0; prv_n0 = cur_n0; prv_ar = cur_ar;
-        cur_m0 = nxt_m0; cur_n0 = nxt_n0; cur_ar = nxt_ar; cur_wr = nxt_wr; t = tn;
-    }
-}
-
 static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float *W, const float *b, const float *sc,
                       const float *sh, float *y, int64_t n, int out_dim, int in_dim, int relu, int bn_blocks, int bm_blocks,
                       int xcd_order)
@@ -1070,32 +787,6 @@ static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float
     return LCREC_OK;
 }
 
-static int launch_pp3(int total_virtual, hipStream_t stream, const float *x, const float *W, const float *b, const float *sc,
-                      const float *sh, float *y, int64_t n, int out_dim, int in_dim, int relu, int bn_blocks, int bm_blocks,
-                      int xcd_order, int sync_epilogue)
-{
-    constexpr size_t lds = (size_t)(2 * 128 + 2 * 128 + 8 * 32) * LDK * sizeof(float);     // 110 592 B
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
-        return v > 8 ? v / 8 * 8 : 8;                // a multiple of 8 keeps a workgroup's tiles on its own XCD
-    }();
-    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_fwd_pp3_kernel<false>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_fwd_pp3_kernel<true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr0 != hipSuccess || attr1 != hipSuccess)
-        return fail(LCREC_EHIP, "linear_forward: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(attr0 != hipSuccess ? attr0 : attr1));
-    const int grid = total_virtual < cus ? total_virtual : cus;
-    if (sc)
-        hipLaunchKernelGGL(linear_fwd_pp3_kernel<true>, dim3((unsigned)grid), dim3(512), lds, stream, x, W, b, sc, sh, y, n, out_dim,
-                           in_dim, relu, bn_blocks, bm_blocks, total_virtual, xcd_order, sync_epilogue);
-    else
-        hipLaunchKernelGGL(linear_fwd_pp3_kernel<false>, dim3((unsigned)grid), dim3(512), lds, stream, x, W, b, sc, sh, y, n, out_dim,
-                           in_dim, relu, bn_blocks, bm_blocks, total_virtual, xcd_order, sync_epilogue);
-    return LCREC_OK;
-}
-
 static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *W, const float *b, const float *sc,
                             const float *sh, int relu, int out_dim, float *y, int tune, hipStream_t stream)
 {
@@ -1106,14 +797,7 @@ static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *
     TraceScope trace(K_LINEAR_PP, stream);
     // K % 32 == 0 (and a tile's operand rows addressable with 31 bits): the VALU-free form
     static const int pp2 = [] { const char *e = getenv("LCREC_GEMM_PP2"); return e ? atoi(e) : 1; }();   // 0: first form only
-    // LCREC_GEMM_PP3=1: the persistent form where its preconditions hold (experimental until measured)
-    static const int pp3 = [] { const char *e = getenv("LCREC_GEMM_PP3"); return e ? atoi(e) : 0; }();   // 2: epilogue not overlapped
-    if (pp3 && in_dim % 64 == 0 && in_dim >= 6 * BK && out_dim % 128 == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31) &&
-        (int64_t)out_dim * 4 * 128 < (1ll << 31)) {
-        int rc = launch_pp3((int)grid, stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune & 1,
-                            pp3 == 2);
-        if (rc) return rc;
-    } else if (pp2 && in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31)) {
+    if (pp2 && in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31)) {
         int rc = launch_pp2(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks,
                             (int)bm_blocks, tune & 1);
         if (rc) return rc;
