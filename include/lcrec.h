@@ -61,6 +61,20 @@ int lcrec_linear_forward(const float *x, int64_t n, int in_dim, const float *W, 
                          const float *bn_scale, const float *bn_shift, int relu, int out_dim,
                          float *y, void *stream);
 
+/* The two backward products of one Linear layer, as autograd derives them for nn.Linear in
+ * MLPLayers (index/models/layers.py:23; driven by loss.backward() at index/trainer.py:117,
+ * SURVEY.md row a9):
+ *   gx [n][in_dim]       = gy [n][out_dim] * W [out_dim][in_dim]
+ *   gw [out_dim][in_dim] = gy^T * x [n][in_dim]
+ * gy is the gradient w.r.t. the layer's pre-activation output (the caller has already applied the
+ * ReLU mask); the bias gradient is the caller's column sum of gy.  Every operand is read in the
+ * layout it is stored in -- no transposed copies -- and every output element is one fp32 fma chain
+ * over the contracted index ascending (out_dim for gx, n for gw), like the forward kernel.
+ * gx_out / gw_out may be NULL to skip a product.  out_dim % 32 == 0 is required for gx, in_dim and
+ * out_dim % 4 == 0 for both; sized for training batches (n * max(in_dim, out_dim) < 2^29). */
+int lcrec_linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim,
+                          float *gx_out, float *gw_out, void *stream);
+
 /* L-level residual quantisation with hard (argmin) assignment.
  * Replaces ResidualVectorQuantizer.forward, index/models/rq.py:39-55, over
  * VectorQuantizer.forward with use_sk=False, index/models/vq.py:63-99

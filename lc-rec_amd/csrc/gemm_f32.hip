@@ -64,6 +64,9 @@ __device__ unsigned long long g_marks[8][4];      // kernel entry, prologue done
 #define LCREC_MARK(slot) do { } while (0)
 #endif
 
+template <int N>
+struct IntC { static constexpr int value = N; };
+
 constexpr int BK = 32;   // K slice per step
 constexpr int LDK = 36;  // padded LDS row length in floats
 
@@ -192,7 +195,12 @@ __device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t r, int
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
+// TA / TB: the A / W operand is given K-MAJOR ([K][M] resp. [K][N] row-major) instead of [M][K] / [N][K].  These are
+// the operand shapes of the two backward products of a Linear layer -- dX = dY W reads W [out][in] as the
+// k-major "W" of an [n][in] output, dW = dY^T X reads dY [n][out] and X [n][in] both k-major -- so no transposed
+// copy of W, dY or X is ever made.  The transposition happens in the LDS write (ds_write2_b32 places the four
+// rows of a 16-byte global load); chain order over k is unchanged.  Requires FAST.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
@@ -237,9 +245,45 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     StageRegs<BN> rw;
     const int nk = (K + BK - 1) / BK;
 
+    static_assert(FAST || (!TA && !TB), "k-major operands need the buffer-load path");
     // FAST (K % 32 == 0): buffer loads + ds_write2_b32 -- no VALU in the staging path; thread p of a pass covers
     // row p/4, k-group p%4; threads beyond a narrow tile get an out-of-range offset (reads 0, stores nothing)
-    const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A, m0, M, BM, K), w_rsrc = tile_rsrc(W, n0, N, BN, K);
+    // k-major operand S [K][R], tile rows r0..: the descriptor starts at column r0 and ends with the last valid
+    // column of row K-1, so k >= K reads 0.0f by the range check; columns past R are masked per thread below
+    auto kmajor_rsrc = [&](const float *base, int64_t r0, int64_t R, int tile_rows) {
+        int64_t cols = R - r0;
+        cols = cols < 0 ? 0 : (cols > tile_rows ? tile_rows : cols);
+        const int64_t bytes = cols > 0 ? ((int64_t)(K - 1) * R + cols) * 4 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + r0), 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t a_rsrc = TA ? kmajor_rsrc(A, m0, M, BM) : tile_rsrc(A, m0, M, BM, K);
+    const __amdgpu_buffer_rsrc_t w_rsrc = TB ? kmajor_rsrc(W, n0, N, BN) : tile_rsrc(W, n0, N, BN, K);
+    // k-major staging: thread p of a pass loads the 16 bytes at (k = p / (ROWS/4), rows 4*(p % (ROWS/4)) .. +3) and
+    // writes them to four LDS rows at k's de-interleaved slot (k steps of 8+ between passes keep the slot's low bits)
+    auto kmajor_load = [&](auto &r, __amdgpu_buffer_rsrc_t rs, auto rows_c, int64_t R, int64_t r0, int kt) {
+        constexpr int ROWS = decltype(rows_c)::value, Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;
+        const int kk = tid / Q, r4 = tid % Q;
+        const bool ok = tid < Q * 32 && r0 + r4 * 4 < R;
+        const int vo = ok ? (int)((kk * R + r4 * 4) * 4) : 0x7fffff00;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            r.v[j >> 1][j & 1] = buffer_load_f32x4(rs, vo, (int)(((int64_t)kt * BK + j * KSTEP) * R * 4));
+    };
+    auto kmajor_store = [&](const auto &r, float *lds, auto rows_c) {
+        constexpr int ROWS = decltype(rows_c)::value, Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;
+        const int kk = tid / Q, r4 = tid % Q;
+        if (tid < Q * 32) {
+            const int slot = (kk & ~7) + ((kk & 1) << 2) + ((kk >> 1) & 3);
+            const uint32_t addr = lds_addr(lds) + (uint32_t)((r4 * 4 * LDK + slot) * 4);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const f32x4 v = r.v[j >> 1][j & 1];
+                const uint32_t a = addr + j * KSTEP * 4;
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:36" ::"v"(a), "v"(v[0]), "v"(v[1]) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:72 offset1:108" ::"v"(a), "v"(v[2]), "v"(v[3]) : "memory");
+            }
+        }
+    };
     const int t_g = ((tid >> 2) * K + (tid & 3) * 8) * 4;
     const uint32_t t_s = (uint32_t)(((tid >> 2) * LDK + (tid & 3) * 8) * 4);
     auto fast_load = [&](auto &r, __amdgpu_buffer_rsrc_t rs, int rows, int kt) {
@@ -261,8 +305,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     };
     auto stage_in = [&](int kt) {
         if constexpr (FAST) {
-            fast_load(ra, a_rsrc, BM, kt);
-            fast_load(rw, w_rsrc, BN, kt);
+            if constexpr (TA) kmajor_load(ra, a_rsrc, IntC<BM>{}, M, m0, kt);
+            else fast_load(ra, a_rsrc, BM, kt);
+            if constexpr (TB) kmajor_load(rw, w_rsrc, IntC<BN>{}, N, n0, kt);
+            else fast_load(rw, w_rsrc, BN, kt);
         } else {
             stage_load<BM>(ra, A, m0, M, K, kt * BK, tid);
             stage_load<BN>(rw, W, n0, N, K, kt * BK, tid);
@@ -270,8 +316,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     };
     auto stage_out = [&]() {
         if constexpr (FAST) {
-            fast_store(ra, As, BM);
-            fast_store(rw, Ws, BN);
+            if constexpr (TA) kmajor_store(ra, As, IntC<BM>{});
+            else fast_store(ra, As, BM);
+            if constexpr (TB) kmajor_store(rw, Ws, IntC<BN>{});
+            else fast_store(rw, Ws, BN);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm stores are invisible to the compiler's counters
         } else {
             stage_store<BM>(ra, As, tid);
@@ -557,8 +605,6 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
 //   * the K loop is unrolled by two so both W buffers are compile-time LDS offsets;
 //   * sched_barriers pin the second half's fragment reads under the first half's MFMAs.
 // ------------------------------------------------------------------------------------------
-template <int N>
-struct IntC { static constexpr int value = N; };
 
 // Measured and rejected on MI355X (tools/gemm_probe.py, TFLOP/s on the 768->2048 / 2048->1024 layers; this form: 141 / 151):
 //   K slice of 64 per phase (half the barriers, 139 KB of LDS)                       133 / 144
@@ -831,6 +877,62 @@ static int launch_linear(const float *x, int64_t n, int in_dim, const float *W, 
         hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN, false>), dim3((unsigned)grid), dim3(256), 0,
                            stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
     return check_launch("linear_fwd_kernel");
+}
+
+// C[M][N] = A * B with A given [M][K] (TA false) or [K][M] (TA true) and B given [K][N] (always k-major here):
+// the two backward products of a Linear layer.  Same tiles and the same dispatch by (M, N) as the forward launches.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool TA>
+static int launch_kmajor(const float *A, const float *B, int64_t M, int N, int K, float *C, hipStream_t stream)
+{
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    const int64_t bm_blocks = (M + BM - 1) / BM;
+    const int bn_blocks = (N + BN - 1) / BN;
+    const int64_t grid = ((bm_blocks + 7) / 8) * 8 * bn_blocks;
+    if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_backward: grid too large");
+    TraceScope trace(BM == 64 ? K_LINEAR_64x64 : BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
+    hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN, true, TA, true>), dim3((unsigned)grid), dim3(256), 0, stream,
+                       A, B, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, C, M, N, K, 0, bn_blocks,
+                       (int)bm_blocks, 1);
+    return check_launch("linear_fwd_kernel (k-major operands)");
+}
+
+template <bool TA>
+static int gemm_kmajor(const float *A, const float *B, int64_t M, int N, int K, float *C, hipStream_t stream)
+{
+    if (N > 64) {
+        const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+        if (tiles128 < 512) return launch_kmajor<2, 2, 1, 1, TA>(A, B, M, N, K, C, stream);
+        return launch_kmajor<2, 2, 2, 2, TA>(A, B, M, N, K, C, stream);
+    }
+    if (N > 32) return launch_kmajor<4, 1, 1, 2, TA>(A, B, M, N, K, C, stream);
+    return launch_kmajor<4, 1, 1, 1, TA>(A, B, M, N, K, C, stream);
+}
+
+int linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim, float *gx, float *gw,
+                    hipStream_t stream)
+{
+    if (n == 0) return LCREC_OK;
+    if (!gy || (gx && !W) || (gw && !x)) return fail(LCREC_EINVAL, "linear_backward: NULL pointer");
+    if (n < 0 || in_dim <= 0 || out_dim <= 0) return fail(LCREC_EINVAL, "linear_backward: bad shape");
+    if (in_dim % 4 != 0 || out_dim % 4 != 0)
+        return fail(LCREC_EUNSUPPORTED, "linear_backward: in_dim=%d / out_dim=%d must be multiples of 4", in_dim, out_dim);
+    if (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)W) & 15) return fail(LCREC_EINVAL, "linear_backward: operands must be 16-byte aligned");
+    const int64_t widest = in_dim > out_dim ? in_dim : out_dim;
+    if ((n + 64) * widest * 4 >= (1ll << 31) || (int64_t)out_dim * in_dim * 4 >= (1ll << 31))
+        return fail(LCREC_EUNSUPPORTED, "linear_backward: operands of %lld x %lld floats exceed the 2 GiB a buffer descriptor spans "
+                                        "(a training batch is expected here)", (long long)n, (long long)widest);
+    if (gx) {
+        // dX [n][in] = dY [n][out] * W [out][in]: A row-major (K = out), B = W as it is stored
+        if (out_dim % BK != 0) return fail(LCREC_EUNSUPPORTED, "linear_backward: out_dim=%d is not a multiple of 32", out_dim);
+        int rc = gemm_kmajor<false>(gy, W, n, in_dim, out_dim, gx, stream);
+        if (rc) return rc;
+    }
+    if (gw) {
+        // dW [out][in] = dY^T * X: A = dY [n][out] and B = X [n][in], both as they are stored (K = n, any length)
+        int rc = gemm_kmajor<true>(gy, x, out_dim, in_dim, (int)n, gw, stream);
+        if (rc) return rc;
+    }
+    return LCREC_OK;
 }
 
 int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const float *b,

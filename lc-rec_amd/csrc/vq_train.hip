@@ -970,23 +970,37 @@ constexpr int CSS_MAX_N = 8192;
 constexpr int CSS_MAX_K = 1024;
 constexpr int CSS_THREADS = 256;
 
+constexpr int CSS_CHUNK = 256;          // rows staged in LDS per pass of the summation
+
 template <int E>
 __global__ __launch_bounds__(CSS_THREADS) void code_stats_sorted_kernel(const int64_t *__restrict__ idx, int64_t idx_stride,
                                                                        const float *__restrict__ resid, int n, int K,
                                                                        float *__restrict__ count, float *__restrict__ sum)
 {
-    __shared__ int skey[CSS_MAX_N];
-    __shared__ int order[CSS_MAX_N];
+    __shared__ __attribute__((aligned(16))) unsigned short skey[CSS_MAX_N];     // code of item i
+    __shared__ unsigned short order[CSS_MAX_N];                                 // items sorted by (code, item)
     __shared__ int start[CSS_MAX_K + 1];
     __shared__ int cursor[CSS_MAX_K];
+    __shared__ __attribute__((aligned(16))) float rows[CSS_CHUNK * E];          // the rows of one chunk, in sorted order
     const int tid = threadIdx.x;
     for (int k = tid; k < K; k += CSS_THREADS) cursor[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += CSS_THREADS) {
-        int k = (int)idx[(int64_t)i * idx_stride];
-        k = k < 0 ? 0 : (k >= K ? K - 1 : k);
-        skey[i] = k;
-        atomicAdd(&cursor[k], 1);            // integer histogram: the totals do not depend on arrival order
+    for (int i0 = 0; i0 < n; i0 += 8 * CSS_THREADS) {            // eight index loads in flight per thread
+        int kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * CSS_THREADS + tid;
+            kk[u] = i < n ? (int)idx[(int64_t)i * idx_stride] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * CSS_THREADS + tid;
+            if (i < n) {
+                const int k = kk[u] < 0 ? 0 : (kk[u] >= K ? K - 1 : kk[u]);
+                skey[i] = (unsigned short)k;
+                atomicAdd(&cursor[k], 1);    // integer histogram: the totals do not depend on arrival order
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {                          // K <= 1024: a serial exclusive scan is ~1 us
@@ -995,44 +1009,66 @@ __global__ __launch_bounds__(CSS_THREADS) void code_stats_sorted_kernel(const in
         start[K] = run;
     }
     __syncthreads();
-    for (int k = tid; k < K; k += CSS_THREADS) {
-        if (blockIdx.x == 0) count[k] = (float)cursor[k];
-        cursor[k] = start[k];
+    if (blockIdx.x == 0)
+        for (int k = tid; k < K; k += CSS_THREADS) count[k] = (float)cursor[k];
+    // This workgroup sums CSS_THREADS / E codes: [k_lo, k_hi).  Stable placement of THEIR items only, by all threads:
+    // thread (code c, segment g) owns items [g*seg, (g+1)*seg) -- it counts its matches, the segment counts of a code
+    // are prefix-summed, then it appends its matches (item order inside a segment, segments in order).
+    constexpr int CPB = CSS_THREADS / E;
+    __shared__ int segcnt[CPB][E + 1];
+    const int k_lo = blockIdx.x * CPB, k_hi = k_lo + CPB < K ? k_lo + CPB : K;
+    {
+        const int c = tid / E, g = tid % E;
+        const unsigned k = (unsigned)(k_lo + c);
+        const int seg = ((n + E - 1) / E + 7) & ~7;
+        const int i_lo = g * seg < n ? g * seg : n, i_hi = (g + 1) * seg < n ? (g + 1) * seg : n;
+        auto walk = [&](auto &&hit) {
+            int i = i_lo;
+            for (; i + 8 <= i_hi; i += 8) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(&skey[i]);
+                const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    if ((w[h] & 0xffffu) == k) hit(i + 2 * h);
+                    if ((w[h] >> 16) == k) hit(i + 2 * h + 1);
+                }
+            }
+            for (; i < i_hi; ++i)
+                if (skey[i] == k) hit(i);
+        };
+        int cnt = 0;
+        if (k_lo + c < K) walk([&](int) { ++cnt; });
+        segcnt[c][g] = cnt;
+        __syncthreads();
+        if (k_lo + c < K) {
+            int pos = start[k];
+            for (int t = 0; t < g; ++t) pos += segcnt[c][t];
+            walk([&](int i) { order[pos++] = (unsigned short)i; });
+        }
     }
     __syncthreads();
-    // stable placement, one chunk of CSS_THREADS items at a time, chunks in item order
-    for (int c0 = 0; c0 < n; c0 += CSS_THREADS) {
-        const int i = c0 + tid;
-        int key = -1, rank = 0, base = 0;
-        if (i < n) {
-            key = skey[i];
-            for (int j = c0; j < i; ++j) rank += (skey[j] == key) ? 1 : 0;   // earlier items of this chunk, same code
-            base = cursor[key];
+    // Per-code sums in item order (bit-identical to the CPU's sequential index_add_).  A code can own most of the
+    // batch (early training), so the chain must not wait on memory: the workgroup's rows are first gathered, in
+    // sorted order and with every load independent, into LDS a chunk at a time; the chains then read LDS.
+    const int p_lo = start[k_lo], p_hi = start[k_hi];
+    const int kq = tid / E, d = tid % E;
+    const int my_lo = k_lo + kq < K ? start[k_lo + kq] : p_hi, my_hi = k_lo + kq < K ? start[k_lo + kq + 1] : p_hi;
+    float acc = 0.f;
+    for (int c0 = p_lo; c0 < p_hi; c0 += CSS_CHUNK) {
+        const int c1 = c0 + CSS_CHUNK < p_hi ? c0 + CSS_CHUNK : p_hi;
+        constexpr int LPR = E / 4;                                   // 16-byte pieces per row
+        for (int q = tid; q < (c1 - c0) * LPR; q += CSS_THREADS) {
+            const int r = q / LPR, piece = q % LPR;
+            *reinterpret_cast<f32x4 *>(&rows[r * E + piece * 4]) =
+                *reinterpret_cast<const f32x4 *>(resid + (int64_t)order[c0 + r] * E + piece * 4);
         }
         __syncthreads();
-        if (i < n) {
-            order[base + rank] = i;
-            atomicAdd(&cursor[key], 1);
-        }
+        const int a = my_lo > c0 ? my_lo : c0, b = my_hi < c1 ? my_hi : c1;
+#pragma unroll 8
+        for (int p = a; p < b; ++p) acc = acc + rows[(p - c0) * E + d];      // the LDS reads run ahead of the add chain
         __syncthreads();
     }
-    // per-code sums in item order.  The walk is a chain of dependent loads (~n/K per thread), so the codes
-    // are spread over the grid: every workgroup repeats the (cheap) sort and sums CSS_THREADS/E codes.
-    const int k = blockIdx.x * (CSS_THREADS / E) + tid / E, d = tid % E;
-    if (k < K) {
-        float acc = 0.f;
-        int p = start[k];
-        const int end = start[k + 1];
-        for (; p + 16 <= end; p += 16) {      // 16 loads in flight, then the additions in item order
-            float v[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = resid[(int64_t)order[p + t] * E + d];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc = acc + v[t];
-        }
-        for (; p < end; ++p) acc = acc + resid[(int64_t)order[p] * E + d];
-        sum[(size_t)k * E + d] = acc;
-    }
+    if (k_lo + kq < K) sum[(size_t)(k_lo + kq) * E + d] = acc;
 }
 
 int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,

@@ -7,8 +7,9 @@ indices) is kept because checkpoints are keyed by it (`encoder.mlp_layers.1.weig
 runs is different:
   * eval / no-grad : one fused fp32-MFMA kernel per layer (bias + folded BatchNorm + ReLU in the
     GEMM epilogue), see csrc/gemm_f32.hip;
-  * training       : the same kernel for the forward GEMM and for both backward GEMMs
-    (dX = dY W, dW = dY^T X), batch-statistics BatchNorm through torch for now.
+  * training       : the same kernel family for the forward GEMM and for both backward GEMMs
+    (dX = dY W, dW = dY^T X; lcrec_linear_backward reads every operand as stored, no transposed
+    copies), batch-statistics BatchNorm through torch for now.
 """
 import torch
 import torch.nn as nn
@@ -35,10 +36,15 @@ class _LinearAct(torch.autograd.Function):
         if ctx.relu:
             gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = ops.linear_forward(gy, weight.t().contiguous())          # [n,out] x [out,in]
-        if ctx.needs_input_grad[1]:
-            gw = ops.linear_forward(gy.t().contiguous(), x.t().contiguous())  # [out,n] x [n,in]
+        out_dim, in_dim = weight.shape
+        if out_dim % 32 == 0 and in_dim % 4 == 0:
+            # both products read gy, x and W as they are stored (k-major operand staging in the kernel)
+            gx, gw = ops.linear_backward(gy, x, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        else:
+            if ctx.needs_input_grad[0]:
+                gx = ops.linear_forward(gy, weight.t().contiguous())          # [n,out] x [out,in]
+            if ctx.needs_input_grad[1]:
+                gw = ops.linear_forward(gy.t().contiguous(), x.t().contiguous())  # [out,n] x [n,in]
         if ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         return gx, gw, gb, None

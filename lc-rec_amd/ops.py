@@ -69,6 +69,24 @@ def linear_forward(x, weight, bias=None, bn_scale=None, bn_shift=None, relu=Fals
     return y
 
 
+def linear_backward(gy, x, weight, need_gx=True, need_gw=True):
+    """(gx, gw) of y = x W^T for a given gy = dL/dy (autograd's LinearBackward; include/lcrec.h,
+    lcrec_linear_backward): gx = gy W, gw = gy^T x, every operand read as stored.  Raises
+    LcrecError(LCREC_EUNSUPPORTED) for shapes the k-major kernels do not cover."""
+    lib = _lib.load()
+    gy, x, weight = _dev(gy, "gy"), _dev(x, "x"), _dev(weight, "weight")
+    n, out_dim = gy.shape
+    in_dim = x.shape[1]
+    if x.shape[0] != n or tuple(weight.shape) != (out_dim, in_dim):
+        raise _lib.LcrecError(f"linear_backward: shapes gy {tuple(gy.shape)}, x {tuple(x.shape)}, W {tuple(weight.shape)}")
+    gx = torch.empty((n, in_dim), dtype=torch.float32, device=gy.device) if need_gx else None
+    gw = torch.empty((out_dim, in_dim), dtype=torch.float32, device=gy.device) if need_gw else None
+    with torch.cuda.device(gy.device):
+        rc = lib.lcrec_linear_backward(_ptr(gy), _ptr(x), _ptr(weight), n, in_dim, out_dim, _ptr(gx), _ptr(gw), _stream_ptr())
+    _lib.check(rc, "lcrec_linear_backward")
+    return gx, gw
+
+
 def flatten_codebooks(codebooks):
     """List of [K_l, e] tensors -> (flat fp32 tensor, [K_l]) in the layout lcrec_rq_assign expects."""
     ks = [int(c.shape[0]) for c in codebooks]

@@ -47,6 +47,28 @@ def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     assert ("linear_fwd_pp_256x128" in trace) == (n >= 8192), trace      # the intended kernel ran
 
 
+@pytest.mark.parametrize("n,k,out", [(2048, 768, 2048), (475, 128, 64), (1000, 64, 32), (300, 2048, 1024), (77, 32, 128),
+                                     (2048, 36, 96), (1, 64, 32)])
+def test_linear_backward_bit_exact(hip, oracle, n, k, out):
+    """lcrec_linear_backward (k-major operand staging, no transposed copies) against the oracle's forward
+    chain on explicitly transposed operands: gx = gy W, gw = gy^T x, one fma chain per output over the
+    contracted index ascending -- including a batch that is not a multiple of the K slice (475, 77, 1)."""
+    rs = _rs(n * 3 + k + out)
+    x = rs.standard_normal((n, k)).astype(np.float32)
+    W = (rs.standard_normal((out, k)) / np.sqrt(k)).astype(np.float32)
+    gy = rs.standard_normal((n, out)).astype(np.float32)
+    gy[rs.random_sample(gy.shape) < 0.4] = 0.0                    # as after a ReLU mask
+    want_gx = oracle.linear(gy, np.ascontiguousarray(W.T), threads=8)
+    want_gw = oracle.linear(np.ascontiguousarray(gy.T), np.ascontiguousarray(x.T), threads=8)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    gx, gw = hip.ops.linear_backward(t(gy), t(x), t(W))
+    assert np.array_equal(gx.cpu().numpy(), want_gx), f"gx max abs diff {np.abs(gx.cpu().numpy() - want_gx).max()}"
+    assert np.array_equal(gw.cpu().numpy(), want_gw), f"gw max abs diff {np.abs(gw.cpu().numpy() - want_gw).max()}"
+    only_gw = hip.ops.linear_backward(t(gy), t(x), t(W), need_gx=False)
+    assert only_gw[0] is None and torch.equal(only_gw[1], gw)
+
+
 @pytest.mark.parametrize("n,e,Ks", [
     (64, 32, [256] * 4),
     (1000, 32, [256] * 4),
