@@ -69,11 +69,18 @@ int lcrec_linear_forward(const float *x, int64_t n, int in_dim, const float *W, 
  * gy is the gradient w.r.t. the layer's pre-activation output (the caller has already applied the
  * ReLU mask); the bias gradient is the caller's column sum of gy.  Every operand is read in the
  * layout it is stored in -- no transposed copies -- and every output element is one fp32 fma chain
- * over the contracted index ascending (out_dim for gx, n for gw), like the forward kernel.
+ * over the contracted index ascending (out_dim for gx), like the forward kernel.  For gw the
+ * contracted index is the batch: it is cut into S = lcrec_linear_backward_splits(n, in_dim, out_dim)
+ * runs of 32*ceil(ceil(n/32)/S) consecutive items (S = 1 for the wide layers, up to 16 for the narrow
+ * ones, so that a small [out_dim][in_dim] output still fills the chip); each run is one fma chain
+ * from 0 and the runs are added in order, ((p0 + p1) + p2) + ...  S depends only on the three sizes.
  * gx_out / gw_out may be NULL to skip a product.  out_dim % 32 == 0 is required for gx, in_dim and
- * out_dim % 4 == 0 for both; sized for training batches (n * max(in_dim, out_dim) < 2^29). */
+ * out_dim % 4 == 0 for both; sized for training batches (n * max(in_dim, out_dim) < 2^29).
+ * workspace: device scratch of lcrec_linear_backward_workspace() bytes (S partial products; 0 if S = 1). */
+int lcrec_linear_backward_splits(int64_t n, int in_dim, int out_dim);
+size_t lcrec_linear_backward_workspace(int64_t n, int in_dim, int out_dim);
 int lcrec_linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim,
-                          float *gx_out, float *gw_out, void *stream);
+                          float *gx_out, float *gw_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* L-level residual quantisation with hard (argmin) assignment.
  * Replaces ResidualVectorQuantizer.forward, index/models/rq.py:39-55, over

@@ -25,7 +25,10 @@ _SIGNATURES = {
     "lcrec_last_error": (ctypes.c_char_p, []),
     "lcrec_linear_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int,
                                             ctypes.c_int, _vp, _vp]),
-    "lcrec_linear_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    "lcrec_linear_backward_splits": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "lcrec_linear_backward_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "lcrec_linear_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                             ctypes.c_size_t, _vp]),
     "lcrec_rq_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                     ctypes.c_int]),
     "lcrec_rq_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),

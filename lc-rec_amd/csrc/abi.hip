@@ -87,10 +87,17 @@ LCREC_API int lcrec_linear_forward(const float *x, int64_t n, int in_dim, const 
     return linear_forward(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, (hipStream_t)stream);
 }
 
-LCREC_API int lcrec_linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim,
-                                    float *gx_out, float *gw_out, void *stream)
+LCREC_API int lcrec_linear_backward_splits(int64_t n, int in_dim, int out_dim) { return linear_backward_splits(n, in_dim, out_dim); }
+
+LCREC_API size_t lcrec_linear_backward_workspace(int64_t n, int in_dim, int out_dim)
 {
-    return linear_backward(gy, x, W, n, in_dim, out_dim, gx_out, gw_out, (hipStream_t)stream);
+    return linear_backward_workspace(n, in_dim, out_dim);
+}
+
+LCREC_API int lcrec_linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim,
+                                    float *gx_out, float *gw_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return linear_backward(gy, x, W, n, in_dim, out_dim, gx_out, gw_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 LCREC_API size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L)

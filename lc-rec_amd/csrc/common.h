@@ -51,8 +51,10 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
                    const float *bn_scale, const float *bn_shift, int relu, int out_dim, float *y,
                    hipStream_t stream);
 
+int linear_backward_splits(int64_t n, int in_dim, int out_dim);
+size_t linear_backward_workspace(int64_t n, int in_dim, int out_dim);
 int linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim, float *gx, float *gw,
-                    hipStream_t stream);
+                    void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 size_t rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,

@@ -204,7 +204,7 @@ template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, 
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
-    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune)
+    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune, int kt_per_split, int64_t split_stride)
 {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -243,7 +243,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 
     StageRegs<BM> ra;
     StageRegs<BN> rw;
-    const int nk = (K + BK - 1) / BK;
+    // split K (backward dW only, where K is the batch and the output is small): workgroup (tile, blockIdx.y) runs the
+    // K-tiles [kt0, nk) of its split and writes a partial result at C + blockIdx.y * split_stride; a second kernel adds
+    // the partials in split order.  Forward launches pass kt_per_split = all K-tiles, gridDim.y = 1.
+    const int nk_all = (K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int nk = kt0 + kt_per_split < nk_all ? kt0 + kt_per_split : nk_all;
+    C += blockIdx.y * split_stride;
 
     static_assert(FAST || (!TA && !TB), "k-major operands need the buffer-load path");
     // FAST (K % 32 == 0): buffer loads + ds_write2_b32 -- no VALU in the staging path; thread p of a pass covers
@@ -327,14 +333,16 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
         }
     };
 
-    stage_in(0);
-    stage_out();
+    if (kt0 < nk) {
+        stage_in(kt0);
+        stage_out();
+    }
     __syncthreads();
 
     const float *a_base = As + (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     const float *w_base = Ws + (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         if (kt + 1 < nk) stage_in(kt + 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -872,44 +880,98 @@ static int launch_linear(const float *x, int64_t n, int in_dim, const float *W, 
     static const int fast = [] { const char *e = getenv("LCREC_GEMM_FAST"); return e ? atoi(e) : 1; }();
     if (fast && in_dim % BK == 0 && (int64_t)in_dim * 4 * (BM + 64) < (1ll << 31))
         hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN, true>), dim3((unsigned)grid), dim3(256), 0,
-                           stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
+                           stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune, 1 << 30,
+                           (int64_t)0);
     else
         hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN, false>), dim3((unsigned)grid), dim3(256), 0,
-                           stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
+                           stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune, 1 << 30,
+                           (int64_t)0);
     return check_launch("linear_fwd_kernel");
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ partial, int splits, int64_t total4,
+                                                          float *__restrict__ out)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total4) return;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(partial);
+    f32x4 acc = p[q];
+    for (int s = 1; s < splits; ++s) acc = acc + p[(int64_t)s * total4 + q];       // run order: ((p0 + p1) + p2) + ...
+    reinterpret_cast<f32x4 *>(out)[q] = acc;
+}
+
 // C[M][N] = A * B with A given [M][K] (TA false) or [K][M] (TA true) and B given [K][N] (always k-major here):
-// the two backward products of a Linear layer.  Same tiles and the same dispatch by (M, N) as the forward launches.
+// the two backward products of a Linear layer.  Same tiles and the same dispatch by (M, N) as the forward launches;
+// `splits` > 1 cuts K into that many runs of K-tiles whose partial products go to `partial` [splits][M][N].
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool TA>
-static int launch_kmajor(const float *A, const float *B, int64_t M, int N, int K, float *C, hipStream_t stream)
+static int launch_kmajor(const float *A, const float *B, int64_t M, int N, int K, float *C, int splits, float *partial,
+                         hipStream_t stream)
 {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     const int64_t bm_blocks = (M + BM - 1) / BM;
     const int bn_blocks = (N + BN - 1) / BN;
     const int64_t grid = ((bm_blocks + 7) / 8) * 8 * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_backward: grid too large");
+    const int nk = (K + BK - 1) / BK;
+    const int per = splits > 1 ? (nk + splits - 1) / splits : 1 << 30;
     TraceScope trace(BM == 64 ? K_LINEAR_64x64 : BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
-    hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN, true, TA, true>), dim3((unsigned)grid), dim3(256), 0, stream,
-                       A, B, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, C, M, N, K, 0, bn_blocks,
-                       (int)bm_blocks, 1);
+    hipLaunchKernelGGL((linear_fwd_kernel<WAVES_M, WAVES_N, TM, TN, true, TA, true>), dim3((unsigned)grid, (unsigned)(splits > 1 ? splits : 1)),
+                       dim3(256), 0, stream, A, B, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                       splits > 1 ? partial : C, M, N, K, 0, bn_blocks, (int)bm_blocks, 1, per, splits > 1 ? M * (int64_t)N : (int64_t)0);
+    if (splits > 1) {
+        const int64_t total4 = M * (int64_t)N / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, partial, splits, total4, C);
+    }
     return check_launch("linear_fwd_kernel (k-major operands)");
 }
 
-template <bool TA>
-static int gemm_kmajor(const float *A, const float *B, int64_t M, int N, int K, float *C, hipStream_t stream)
+// which tile shape a (M, N) output gets: 0 = 64x64, 1 = 128x128, 2 = 128x64, 3 = 128x32 (the forward rule)
+static int kmajor_shape(int64_t M, int N)
 {
-    if (N > 64) {
-        const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-        if (tiles128 < 512) return launch_kmajor<2, 2, 1, 1, TA>(A, B, M, N, K, C, stream);
-        return launch_kmajor<2, 2, 2, 2, TA>(A, B, M, N, K, C, stream);
+    if (N > 64) return ((M + 127) / 128) * ((N + 127) / 128) < 512 ? 0 : 1;
+    return N > 32 ? 2 : 3;
+}
+
+template <bool TA>
+static int gemm_kmajor(const float *A, const float *B, int64_t M, int N, int K, float *C, int splits, float *partial,
+                       hipStream_t stream)
+{
+    switch (kmajor_shape(M, N)) {
+    case 0: return launch_kmajor<2, 2, 1, 1, TA>(A, B, M, N, K, C, splits, partial, stream);
+    case 1: return launch_kmajor<2, 2, 2, 2, TA>(A, B, M, N, K, C, splits, partial, stream);
+    case 2: return launch_kmajor<4, 1, 1, 2, TA>(A, B, M, N, K, C, splits, partial, stream);
+    default: return launch_kmajor<4, 1, 1, 1, TA>(A, B, M, N, K, C, splits, partial, stream);
     }
-    if (N > 32) return launch_kmajor<4, 1, 1, 2, TA>(A, B, M, N, K, C, stream);
-    return launch_kmajor<4, 1, 1, 1, TA>(A, B, M, N, K, C, stream);
+}
+
+// dW = dY^T X contracts over the batch: a [out][in] output of a narrow layer is a handful of tiles, each a serial
+// chain of n/32 K-tiles (66 us at n = 2048 whatever the layer).  So K is cut into S runs of K-tiles -- S chosen to put
+// at least ~512 workgroups on the chip, at least 4 K-tiles per run, at most 16 runs -- and the S partial products are
+// added in run order.  This is part of the arithmetic contract of lcrec_linear_backward (include/lcrec.h): gw is the
+// ordered sum of S fma chains, S = lcrec_linear_backward_splits(n, in_dim, out_dim).
+int linear_backward_splits(int64_t n, int in_dim, int out_dim)
+{
+    static const int cap = [] { const char *e = getenv("LCREC_GEMM_SPLITK"); return e ? atoi(e) : 16; }();
+    const int shape = kmajor_shape(out_dim, in_dim);
+    const int bm = shape == 0 ? 64 : 128, bn = shape == 0 ? 64 : shape == 1 ? 128 : shape == 2 ? 64 : 32;
+    const int64_t tiles = ((out_dim + bm - 1) / bm) * (int64_t)((in_dim + bn - 1) / bn);
+    const int64_t nk = (n + BK - 1) / BK;
+    int64_t s = 512 / (tiles > 0 ? tiles : 1);
+    if (s > nk / 4) s = nk / 4;
+    if (s > cap) s = cap;
+    if (s < 2) return 1;
+    const int64_t per = (nk + s - 1) / s;          // K-tiles per run; the count returned has no empty run
+    return (int)((nk + per - 1) / per);
+}
+
+size_t linear_backward_workspace(int64_t n, int in_dim, int out_dim)
+{
+    const int s = linear_backward_splits(n, in_dim, out_dim);
+    return s > 1 ? (size_t)s * out_dim * in_dim * sizeof(float) : 0;
 }
 
 int linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim, float *gx, float *gw,
-                    hipStream_t stream)
+                    void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     if (n == 0) return LCREC_OK;
     if (!gy || (gx && !W) || (gw && !x)) return fail(LCREC_EINVAL, "linear_backward: NULL pointer");
@@ -924,12 +986,16 @@ int linear_backward(const float *gy, const float *x, const float *W, int64_t n, 
     if (gx) {
         // dX [n][in] = dY [n][out] * W [out][in]: A row-major (K = out), B = W as it is stored
         if (out_dim % BK != 0) return fail(LCREC_EUNSUPPORTED, "linear_backward: out_dim=%d is not a multiple of 32", out_dim);
-        int rc = gemm_kmajor<false>(gy, W, n, in_dim, out_dim, gx, stream);
+        int rc = gemm_kmajor<false>(gy, W, n, in_dim, out_dim, gx, 1, nullptr, stream);
         if (rc) return rc;
     }
     if (gw) {
         // dW [out][in] = dY^T * X: A = dY [n][out] and B = X [n][in], both as they are stored (K = n, any length)
-        int rc = gemm_kmajor<true>(gy, x, out_dim, in_dim, (int)n, gw, stream);
+        const int splits = linear_backward_splits(n, in_dim, out_dim);
+        const size_t need = linear_backward_workspace(n, in_dim, out_dim);
+        if (splits > 1 && (!workspace || workspace_bytes < need))
+            return fail(LCREC_EWORKSPACE, "linear_backward: workspace %zu B < required %zu B", workspace_bytes, need);
+        int rc = gemm_kmajor<true>(gy, x, out_dim, in_dim, (int)n, gw, splits, reinterpret_cast<float *>(workspace), stream);
         if (rc) return rc;
     }
     return LCREC_OK;

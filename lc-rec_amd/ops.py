@@ -82,9 +82,17 @@ def linear_backward(gy, x, weight, need_gx=True, need_gw=True):
     gx = torch.empty((n, in_dim), dtype=torch.float32, device=gy.device) if need_gx else None
     gw = torch.empty((out_dim, in_dim), dtype=torch.float32, device=gy.device) if need_gw else None
     with torch.cuda.device(gy.device):
-        rc = lib.lcrec_linear_backward(_ptr(gy), _ptr(x), _ptr(weight), n, in_dim, out_dim, _ptr(gx), _ptr(gw), _stream_ptr())
+        nbytes = lib.lcrec_linear_backward_workspace(n, in_dim, out_dim) if need_gw else 0
+        ws = _workspace(nbytes, gy.device)
+        rc = lib.lcrec_linear_backward(_ptr(gy), _ptr(x), _ptr(weight), n, in_dim, out_dim, _ptr(gx), _ptr(gw), _ptr(ws),
+                                       ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_linear_backward")
     return gx, gw
+
+
+def linear_backward_splits(n, in_dim, out_dim):
+    """Number of batch runs whose partial products make up gw (part of the arithmetic contract, include/lcrec.h)."""
+    return int(_lib.load().lcrec_linear_backward_splits(n, in_dim, out_dim))
 
 
 def flatten_codebooks(codebooks):

@@ -225,3 +225,20 @@ def kmeans_lloyd(x, init, iters, tol=1e-4):
         if shift <= limit:
             break
     return c, done
+
+
+def linear_backward(gy, x, W, splits=1, threads=1):
+    """(gx, gw) of y = x W^T for gy = dL/dy -- what autograd derives for nn.Linear (reference
+    index/models/layers.py:23 under loss.backward(), index/trainer.py:117), in the arithmetic of
+    lcrec_linear_backward (include/lcrec.h): gx = gy W as one fma chain per element over out_dim;
+    gw = gy^T x as `splits` runs of 32*ceil(ceil(n/32)/splits) consecutive items, each run one fma chain
+    from 0, the runs added in order."""
+    gy, x, W = _f32(gy), _f32(x), _f32(W)
+    n = gy.shape[0]
+    gx = linear(gy, np.ascontiguousarray(W.T), threads=threads)
+    per = -(-(-(-n // 32)) // splits) * 32
+    gw = None
+    for lo in range(0, n, per):
+        part = linear(np.ascontiguousarray(gy[lo:lo + per].T), np.ascontiguousarray(x[lo:lo + per].T), threads=threads)
+        gw = part if gw is None else (gw + part).astype(np.float32)
+    return gx, gw

@@ -50,16 +50,18 @@ def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
 @pytest.mark.parametrize("n,k,out", [(2048, 768, 2048), (475, 128, 64), (1000, 64, 32), (300, 2048, 1024), (77, 32, 128),
                                      (2048, 36, 96), (1, 64, 32)])
 def test_linear_backward_bit_exact(hip, oracle, n, k, out):
-    """lcrec_linear_backward (k-major operand staging, no transposed copies) against the oracle's forward
-    chain on explicitly transposed operands: gx = gy W, gw = gy^T x, one fma chain per output over the
-    contracted index ascending -- including a batch that is not a multiple of the K slice (475, 77, 1)."""
+    """lcrec_linear_backward (k-major operand staging, no transposed copies) against the oracle's restatement
+    on explicitly transposed operands: gx = gy W one fma chain per output; gw = gy^T x as the ordered sum of
+    lcrec_linear_backward_splits() runs over the batch -- including batches that are not a multiple of the
+    K slice (475, 77, 1) and narrow layers that split 16 ways."""
     rs = _rs(n * 3 + k + out)
     x = rs.standard_normal((n, k)).astype(np.float32)
     W = (rs.standard_normal((out, k)) / np.sqrt(k)).astype(np.float32)
     gy = rs.standard_normal((n, out)).astype(np.float32)
     gy[rs.random_sample(gy.shape) < 0.4] = 0.0                    # as after a ReLU mask
-    want_gx = oracle.linear(gy, np.ascontiguousarray(W.T), threads=8)
-    want_gw = oracle.linear(np.ascontiguousarray(gy.T), np.ascontiguousarray(x.T), threads=8)
+    splits = hip.ops.linear_backward_splits(n, k, out)
+    assert splits == 1 or (n >= 256 and 2 <= splits <= 16)
+    want_gx, want_gw = oracle.linear_backward(gy, x, W, splits=splits, threads=8)
     dev = torch.device("cuda:0")
     t = lambda a: torch.from_numpy(a).to(dev)
     gx, gw = hip.ops.linear_backward(t(gy), t(x), t(W))
