@@ -24,7 +24,8 @@ int fail(int code, const char *fmt, ...)
 const char *const kKernelNames[K_COUNT] = {"linear_fwd_128x128", "linear_fwd_128x64", "linear_fwd_128x32",
                                            "rq_assign", "rq_sse_finalize", "vq_distance", "sinkhorn",
                                            "sinkhorn_small", "rq_apply_level", "code_stats", "ema_update",
-                                           "collision_groups", "linear_fwd_pp_256x128", "linear_fwd_64x64"};
+                                           "collision_groups", "linear_fwd_pp_256x128", "linear_fwd_64x64", "sinkhorn_slab",
+                                           "sinkhorn_tiny"};
 
 struct TraceRec { int kernel; hipEvent_t start, stop; };
 static std::mutex g_trace_mu;

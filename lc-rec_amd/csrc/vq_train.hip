@@ -133,6 +133,21 @@ struct SkBig {
     double eps;
 };
 
+// x / d exactly as a division, cheaply when d is a power of two: then 1/d is exact and x * (1/d) is the correctly
+// rounded value of the same real number, i.e. the same bits as x / d (the reference divides by B and by K every
+// iteration, layers.py:100-104; K = 256 or 1024 and the batch / most collision groups are powers of two).  An fp64
+// division is ~15 instructions; these two were half of all divisions in the solver.
+struct ExactDiv {
+    double d, inv;
+    bool pow2;
+    __device__ __forceinline__ explicit ExactDiv(double v) : d(v), inv(1.0 / v)
+    {
+        const unsigned long long bits = __double_as_longlong(v);
+        pow2 = v > 0.0 && (bits & 0x000fffffffffffffull) == 0;      // zero mantissa: v = 2^e
+    }
+    __device__ __forceinline__ double operator()(double x) const { return pow2 ? x * inv : x / d; }
+};
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(SkBig p, int mode, 
 #pragma unroll
     for (int c = 0; c < SK_MAXC; ++c) acc[c] = 0.0;
     const double Bd = (double)p.B, Kd = (double)p.K;
+    const ExactDiv divB(Bd), divK(Kd);
     for (int rr = wave; rr < SK_ROWS; rr += WAVES) {
         const int64_t row = (int64_t)blockIdx.x * SK_ROWS + rr;
         if (row >= p.B) break;
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(SkBig p, int mode, 
             if (j < p.K) {
                 double v = p.Q[row * p.K + j];
                 if (mode == 0) v = v / total;
-                else { v = v / colsum[j]; v = v / Kd; }
+                else { v = v / colsum[j]; v = divK(v); }
                 q[c] = v;
                 rs += v;
             }
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(SkBig p, int mode, 
             const int j = lane + 64 * c;
             if (j < p.K) {
                 double v = q[c] / rs;
-                v = v / Bd;
+                v = divB(v);
                 p.Q[row * p.K + j] = v;
                 acc[c] += v;
             }
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_final_kernel(SkBig p, int src, 
     }
     __syncthreads();
     const double Bd = (double)p.B, Kd = (double)p.K;
+    const ExactDiv divB(Bd), divK(Kd);
     for (int rr = wave; rr < SK_ROWS; rr += SK_THREADS / 64) {
         const int64_t row = (int64_t)blockIdx.x * SK_ROWS + rr;
         if (row >= p.B) break;
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_final_kernel(SkBig p, int src, 
         int bj = 0;
         for (int j = lane; j < p.K; j += 64) {
             double v = p.Q[row * p.K + j] / colsum[j];
-            v = v / Kd;
+            v = divK(v);
             v = v * Bd;
             if (v > best) { best = v; bj = j; }
         }
@@ -280,6 +297,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_final_kernel(SkBig p, int src, 
 constexpr int SKS_MAX = 16384;   // doubles of LDS for Q (128 KB)
 constexpr int SKS_THREADS = 256;
 
+template <int THREADS>
 __device__ __forceinline__ double block_sum(double v, double *scratch)
 {
     v = wave_sum(v);
@@ -287,19 +305,19 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.0;
-    for (int w = 0; w < SKS_THREADS / 64; ++w) s += scratch[w];
+    for (int w = 0; w < THREADS / 64; ++w) s += scratch[w];
     return s;
 }
 
-template <int E, bool GLOBALQ>
-__global__ __launch_bounds__(SKS_THREADS) void sk_small_kernel(const float *__restrict__ r, const float *__restrict__ cb,
+template <int E, bool GLOBALQ, int THREADS>
+__global__ __launch_bounds__(THREADS) void sk_small_kernel(const float *__restrict__ r, const float *__restrict__ cb,
                                                               int K, const int64_t *__restrict__ offs,
                                                               double eps, int iters, int64_t *idx_out,
                                                               int64_t idx_stride, double *qslab)
 {
     extern __shared__ __attribute__((aligned(16))) double sks_sm[];
-    __shared__ double scratch[SKS_THREADS / 64];
-    __shared__ float fred[2][SKS_THREADS / 64];
+    __shared__ double scratch[THREADS / 64];
+    __shared__ float fred[2][THREADS / 64];
     const int64_t i0 = offs[3 * blockIdx.x];           // offs holds (begin, end, slab offset in doubles) triples
     const int g = (int)(offs[3 * blockIdx.x + 1] - i0);
     if (g <= 0) return;
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_small_kernel(const float *__re
 
     // distances, fp32 canonical chains; thread j owns code j (+256, ...)
     float lo = __builtin_inff(), hi = -__builtin_inff();
-    for (int j = tid; j < K; j += SKS_THREADS) {
+    for (int j = tid; j < K; j += THREADS) {
         float c[E], cc;
         load_code_row<E>(cb, K, j, c, cc);
         for (int t = 0; t < g; ++t) {
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_small_kernel(const float *__re
     }
     if (lane == 0) { fred[0][wave] = lo; fred[1][wave] = hi; }
     __syncthreads();
-    for (int w = 0; w < SKS_THREADS / 64; ++w) { lo = fred[0][w] < lo ? fred[0][w] : lo; hi = fred[1][w] > hi ? fred[1][w] : hi; }
+    for (int w = 0; w < THREADS / 64; ++w) { lo = fred[0][w] < lo ? fred[0][w] : lo; hi = fred[1][w] > hi ? fred[1][w] : hi; }
     const float middle = (hi + lo) / 2.0f;
     const float amplitude = (hi - middle) + 1e-5f;
 
@@ -346,8 +364,8 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_small_kernel(const float *__re
     double part = 0.0;
     {
         // each thread converts a contiguous chunk, highest chunk first is not needed: read all into registers per pass
-        // pass structure: chunks of SKS_THREADS elements from the END; element q (fp32 at byte 4q) -> fp64 at byte 8q >= 4q
-        for (int base = ((total_el - 1) / SKS_THREADS) * SKS_THREADS; base >= 0; base -= SKS_THREADS) {
+        // pass structure: chunks of THREADS elements from the END; element q (fp32 at byte 4q) -> fp64 at byte 8q >= 4q
+        for (int base = ((total_el - 1) / THREADS) * THREADS; base >= 0; base -= THREADS) {
             const int q = base + tid;
             float dv = 0.f;
             if (q < total_el) dv = dmat[q];
@@ -361,35 +379,36 @@ __global__ __launch_bounds__(SKS_THREADS) void sk_small_kernel(const float *__re
             __syncthreads();
         }
     }
-    const double total = block_sum(part, scratch);
-    for (int q = tid; q < total_el; q += SKS_THREADS) Q[q] = Q[q] / total;
+    const double total = block_sum<THREADS>(part, scratch);
+    for (int q = tid; q < total_el; q += THREADS) Q[q] = Q[q] / total;
     __syncthreads();
     const double Bd = (double)g, Kd = (double)K;
+    const ExactDiv divB(Bd), divK(Kd);
     for (int it = 0; it < iters; ++it) {
-        for (int t = wave; t < g; t += SKS_THREADS / 64) {          // row sums (layers.py:99)
+        for (int t = wave; t < g; t += THREADS / 64) {          // row sums (layers.py:99)
             double s = 0.0;
             for (int j = lane; j < K; j += 64) s += Q[(size_t)t * K + j];
             s = wave_sum(s);
             if (lane == 0) rsum[t] = s;
         }
         __syncthreads();
-        for (int j = tid; j < K; j += SKS_THREADS) {                 // Q /= rowsum; Q /= B; column sums (:100-103)
+        for (int j = tid; j < K; j += THREADS) {                 // Q /= rowsum; Q /= B; column sums (:100-103)
             double s = 0.0;
             for (int t = 0; t < g; ++t) {
                 double v = Q[(size_t)t * K + j] / rsum[t];
-                v = v / Bd;
+                v = divB(v);
                 Q[(size_t)t * K + j] = v;
                 s += v;
             }
             csum[j] = s;
             for (int t = 0; t < g; ++t) {                            // Q /= colsum; Q /= K (:103-104)
                 double v = Q[(size_t)t * K + j] / s;
-                Q[(size_t)t * K + j] = v / Kd;
+                Q[(size_t)t * K + j] = divK(v);
             }
         }
         __syncthreads();
     }
-    for (int t = wave; t < g; t += SKS_THREADS / 64) {               // Q *= B; argmax (:107, vq.py:83)
+    for (int t = wave; t < g; t += THREADS / 64) {               // Q *= B; argmax (:107, vq.py:83)
         double best = -1.0;
         int bj = 0;
         for (int j = lane; j < K; j += 64) {
@@ -541,25 +560,31 @@ static size_t sk_big_bytes(int64_t B, int K)
            align_up((size_t)2 * nblk * K * sizeof(double), 256) + align_up((size_t)nblk * sizeof(double), 256) + 256;
 }
 
-// Size classes of a group of sz rows (see sinkhorn_assign): 0 = tiny (Q <= 16 KB of LDS), 1 = fits the
-// LDS budget, 2 = Q in the workspace slab, one workgroup per group, 3 = batch-sized (multi-launch / persistent).
+// Size classes of a group of sz rows (see sinkhorn_assign): 0..3 = Q in LDS, allocation 16 / 32 / 64 / 128 KB (so that
+// pairs and triples -- the bulk of a collision round -- run eight workgroups to a CU, and a 9-row group is not charged
+// a 64-row allocation), SK_SLAB = Q in the workspace slab, one 1024-thread workgroup per group, SK_BATCH = batch-sized
+// (persistent / multi-launch solver).
 constexpr int64_t SKS_TINY = 2048;              // doubles: groups of <= 8 items at K = 256
 constexpr int64_t SKS_SLAB_MAX_ROWS = 4096;     // a larger group is a training-batch-sized problem
+constexpr int SK_SLAB = 4, SK_BATCH = 5;
 
 static inline size_t sk_group_doubles(int64_t g, int K) { return (size_t)g * K + (size_t)((g + 1) & ~(int64_t)1) + K; }
 
 static inline int sk_class(int64_t sz, int K)
 {
-    if (sz * K <= SKS_TINY) return 0;
-    if (sz * K <= SKS_MAX) return 1;
-    return sz <= SKS_SLAB_MAX_ROWS ? 2 : 3;
+    const int64_t q = sz * K;
+    if (q <= SKS_TINY) return 0;
+    if (q <= 2 * SKS_TINY) return 1;
+    if (q <= 4 * SKS_TINY) return 2;
+    if (q <= SKS_MAX) return 3;
+    return sz <= SKS_SLAB_MAX_ROWS ? SK_SLAB : SK_BATCH;
 }
 
 // slab_ok: whether the mid-sized groups (class 2) of this call run side by side, one workgroup each, or one after
 // another as batch-sized problems.  One workgroup walks its g x K matrix ~5 times per iteration out of L2: about
-// 5 us per row at K = 256 for 50 iterations; a batch-sized solve costs ~0.7 ms whatever its size.  A training
-// step's single 2048-row group must take the batch path (0.8 ms, not 10); a collision round's hundred groups of
-// 65..3000 rows must not (15 ms side by side, not 80 ms in a row).
+// 1.5 us per row at K = 256 for 50 iterations (1024 threads); a batch-sized solve costs ~0.7 ms whatever its size.
+// A training step's single 2048-row group must take the batch path (0.7 ms, not 3); a collision round's hundred
+// groups of 65..3000 rows must not (4 ms side by side, not 80 ms in a row).
 struct SkPlan { int64_t slab_doubles; int64_t biggest; int n_slab; bool slab_ok; };
 
 static SkPlan sk_plan(int K, const int64_t *offs, int G)
@@ -571,11 +596,11 @@ static SkPlan sk_plan(int K, const int64_t *offs, int G)
         const int64_t sz = offs[g + 1] - offs[g];
         if (sz <= 0) continue;
         const int cls = sk_class(sz, K);
-        if (cls == 2) { p.slab_doubles += (int64_t)sk_group_doubles(sz, K); ++n_mid; if (sz > mid_max) mid_max = sz; }
-        if (cls >= 2 && sz > mid_biggest) mid_biggest = sz;
-        if (cls == 3 && sz > p.biggest) p.biggest = sz;
+        if (cls == SK_SLAB) { p.slab_doubles += (int64_t)sk_group_doubles(sz, K); ++n_mid; if (sz > mid_max) mid_max = sz; }
+        if (cls >= SK_SLAB && sz > mid_biggest) mid_biggest = sz;
+        if (cls == SK_BATCH && sz > p.biggest) p.biggest = sz;
     }
-    const double side_by_side_us = (double)mid_max * 5.0 * (K / 256.0) * ((n_mid + 255) / 256);
+    const double side_by_side_us = (double)mid_max * 1.5 * (K / 256.0) * ((n_mid + 255) / 256);
     p.slab_ok = n_mid > 0 && side_by_side_us <= 700.0 * n_mid;
     if (p.slab_ok) {
         p.n_slab = n_mid;
@@ -611,7 +636,7 @@ size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G)
 constexpr int SKP_THREADS = 512;
 constexpr int SKP_WAVES = SKP_THREADS / 64;
 constexpr int SKP_MAX_BLOCKS = 128;
-constexpr unsigned SKP_SPIN_LIMIT = 20u * 1000u * 1000u;     // ~ seconds of polling with s_sleep
+constexpr unsigned SKP_SPIN_LIMIT = 40u * 1000u * 1000u;     // ~ seconds of polling with s_sleep
 
 struct SkPersist {
     const float *d;        // [B][K] fp32 distances
@@ -636,7 +661,7 @@ __device__ __forceinline__ void skp_grid_barrier(unsigned *counter, unsigned tar
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > SKP_SPIN_LIMIT) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -658,6 +683,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
     const int K = p.K;
     const int64_t row0 = (int64_t)blockIdx.x * ROWS + wave * RW;
     const double Bd = (double)p.B, Kd = (double)K;
+    const ExactDiv divB(Bd), divK(Kd);
     unsigned phase = 0;
 
     const float hi = ord2f(p.minmax[1]), lo = ord2f(p.minmax[0]);
@@ -709,7 +735,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
                 if (row0 + r < p.B && j < K) {
                     double v = q[r][c];
                     if (it == 0) v = v / total;
-                    else { v = v / colsum[j]; v = v / Kd; }
+                    else { v = v / colsum[j]; v = divK(v); }
                     q[r][c] = v;
                     rs += v;
                 }
@@ -720,7 +746,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
                 const int j = lane + 64 * c;
                 if (row0 + r < p.B && j < K) {
                     double v = q[r][c] / rs;
-                    v = v / Bd;
+                    v = divB(v);
                     q[r][c] = v;
                     acc[c] += v;
                 }
@@ -745,6 +771,13 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
         for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
             double s = 0.0;
             int b = 0;
+            for (; b + 64 <= p.nblk; b += 64) {     // 64 loads in flight (one L2 round trip), then the adds in workgroup order
+                double v[64];
+#pragma unroll
+                for (int t = 0; t < 64; ++t) v[t] = __builtin_nontemporal_load(cp + (size_t)(b + t) * K + j);
+#pragma unroll
+                for (int t = 0; t < 64; ++t) s += v[t];
+            }
             for (; b + 16 <= p.nblk; b += 16) {
                 double v[16];
 #pragma unroll
@@ -766,7 +799,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
             const int j = lane + 64 * c;
             if (row0 + r < p.B && j < K) {
                 double v = q[r][c] / colsum[j];
-                v = v / Kd;
+                v = divK(v);
                 v = v * Bd;
                 if (v > best) { best = v; bj = j; }
             }
@@ -854,14 +887,15 @@ template <int E, bool GLOBALQ>
 static int launch_sk_small(const float *r, const float *cb, int K, const int64_t *triples_dev, int G, int maxg, double eps,
                            int iters, int64_t *idx_out, int64_t idx_stride, double *qslab, hipStream_t stream)
 {
+    constexpr int THREADS = GLOBALQ ? 1024 : SKS_THREADS;
     const size_t lds = GLOBALQ ? 0 : sk_group_doubles(maxg, K) * sizeof(double);
-    auto kern = sk_small_kernel<E, GLOBALQ>;
+    auto kern = sk_small_kernel<E, GLOBALQ, THREADS>;
     if (lds > 48 * 1024) {
         hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(he));
     }
-    TraceScope trace(K_SINKHORN_SMALL, stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(SKS_THREADS), lds, stream, r, cb, K, triples_dev, eps, iters, idx_out,
+    TraceScope trace(GLOBALQ ? K_SINKHORN_SLAB : (int64_t)maxg * K <= SKS_TINY ? K_SINKHORN_TINY : K_SINKHORN_SMALL, stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(THREADS), lds, stream, r, cb, K, triples_dev, eps, iters, idx_out,
                        idx_stride, qslab);
     return check_launch("sk_small_kernel");
 }
@@ -897,20 +931,21 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
     double *qslab = reinterpret_cast<double *>(ws);
     ws += align_up((size_t)plan.slab_doubles * sizeof(double), 256);
 
-    // Size classes, one launch each: [0] tiny and [1] LDS-sized groups keep Q in LDS, [2] mid-sized
-    // groups keep it in their slice of the slab; anything larger is a batch-sized problem (below).
+    // Size classes, one launch each (see sk_class): four LDS allocations, then the slab; anything larger is a
+    // batch-sized problem (below).
+    constexpr int NCLS = SK_SLAB + 1;
     std::vector<int64_t> triples;
     triples.reserve((size_t)3 * G);
-    int count[3] = {0, 0, 0}, maxg[3] = {0, 0, 0};
-    for (int cls = 0; cls < 3; ++cls) {
+    int count[NCLS] = {0}, maxg[NCLS] = {0};
+    for (int cls = 0; cls < NCLS; ++cls) {
         int64_t slab = 0;
         for (int g = 0; g < G; ++g) {
             const int64_t sz = offs[g + 1] - offs[g];
-            if (sz <= 0 || sk_class(sz, K) != cls || (cls == 2 && !plan.slab_ok)) continue;
+            if (sz <= 0 || sk_class(sz, K) != cls || (cls == SK_SLAB && !plan.slab_ok)) continue;
             triples.push_back(offs[g]);
             triples.push_back(offs[g + 1]);
-            triples.push_back(cls == 2 ? slab : 0);
-            if (cls == 2) slab += (int64_t)sk_group_doubles(sz, K);
+            triples.push_back(cls == SK_SLAB ? slab : 0);
+            if (cls == SK_SLAB) slab += (int64_t)sk_group_doubles(sz, K);
             ++count[cls];
             if (sz > maxg[cls]) maxg[cls] = (int)sz;
         }
@@ -920,10 +955,10 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
         if (he == hipSuccess) he = hipStreamSynchronize(stream);   // triples is a host temporary
         if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn_assign: %s", hipGetErrorString(he));
         const int64_t *t = triples_dev;
-        for (int cls = 0; cls < 3; ++cls) {
+        for (int cls = 0; cls < NCLS; ++cls) {
             if (!count[cls]) continue;
-            int rc = cls == 2 ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab, stream)
-                              : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, stream);
+            int rc = cls == SK_SLAB ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab, stream)
+                                    : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, stream);
             if (rc) return rc;
             t += (size_t)3 * count[cls];
         }
@@ -932,7 +967,7 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
     for (int g = 0; g < G; ++g) {
         const int64_t sz = offs[g + 1] - offs[g];
         const int cls = sz > 0 ? sk_class(sz, K) : -1;
-        if (cls == 3 || (cls == 2 && !plan.slab_ok)) {
+        if (cls == SK_BATCH || (cls == SK_SLAB && !plan.slab_ok)) {
             int rc = sinkhorn_big(r + offs[g] * e, sz, e, cb, K, eps, iters, idx_out + offs[g] * idx_stride, idx_stride, ws, stream);
             if (rc) return rc;
         }

@@ -184,7 +184,7 @@ def test_sinkhorn_training_batch(hip, B, K, e):
     if B >= 1000:
         # a lone batch-sized problem must take the multi-workgroup solver, not the one-workgroup-per-group
         # kernel of the collision rounds (that is 10 ms instead of 0.8 ms per training step)
-        assert "sinkhorn" in trace and "sinkhorn_small" not in trace, trace
+        assert "sinkhorn" in trace and not ({"sinkhorn_small", "sinkhorn_slab", "sinkhorn_tiny"} & set(trace)), trace
 
 
 def test_sinkhorn_golden_fixture(hip):
