@@ -204,7 +204,7 @@ def main():
 
     # Algorithmic flops per GEMM kernel: replay the library's dispatch rule (gemm_f32.hip, linear_forward)
     # over the chunks lcrec_encode_assign walks (131072 rows each).
-    def gemm_kernel_for(rows, out):
+    def gemm_kernel_for(rows, out, k):
         if out <= 32:
             return "linear_fwd_128x32"
         if out <= 64:
@@ -213,7 +213,7 @@ def main():
         rounds = -(-pp_tiles // 256)
         fits = pp_tiles >= 256 and (rounds >= 8 or pp_tiles * 5 >= rounds * 256 * 4)
         forced = os.environ.get("LCREC_GEMM_PP", "-1")
-        if forced == "1" or (forced != "0" and fits):
+        if k % 32 == 0 and (forced == "1" or (forced != "0" and fits)):
             return "linear_fwd_pp_256x128"
         return "linear_fwd_64x64" if -(-rows // 128) * -(-out // 128) < 512 else "linear_fwd_128x128"
 
@@ -223,7 +223,7 @@ def main():
         rows = min(131072, n - lo)
         for l in range(len(dims) - 1):
             out = dims[l + 1]
-            kname = gemm_kernel_for(rows, out)
+            kname = gemm_kernel_for(rows, out, dims[l])
             flops[kname] = flops.get(kname, 0.0) + 2.0 * rows * dims[l] * out * args.steps
             # read the activations and the weights once, write the outputs once
             alg_bytes[kname] = alg_bytes.get(kname, 0.0) + 4.0 * (rows * dims[l] + out * dims[l] + rows * out) * args.steps

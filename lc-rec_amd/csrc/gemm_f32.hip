@@ -11,33 +11,28 @@
 // fp32 fma chain over k ascending from 0.  v_mfma_f32_32x32x2_f32 computes
 // D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) with k0 = lanes 0-31, k1 = lanes 32-63,
 // so feeding it k = 2s (low half) and 2s+1 (high half) for s ascending, into one
-// accumulator, reproduces the chain exactly.  There is no split-K.
+// accumulator, reproduces the chain exactly.  The forward product has no split-K; the backward product
+// dW = dY^T X is an ordered sum of a few such chains over runs of the batch (linear_backward, below).
 //
 // Two kernels, one arithmetic (the dispatch is at the bottom of the file):
-//   linear_fwd_kernel<WM,WN,TM,TN>  256 threads = 4 waves, block tile (WM*TM*32) x (WN*TN*32): 128x128 for
-//                                   mid-sized launches, 64x64 for batch-sized ones, 128x64 / 128x32 for the
-//                                   narrow tail layers; several workgroups per CU hide each other's stalls;
-//   linear_fwd_pp_kernel            512 threads, 256x128 tile, for chunk-sized launches: the two waves of a
-//                                   SIMD alternate between "64 MFMAs" and "stage the next tile" (see there).
+//   linear_fwd_kernel<WM,WN,TM,TN,...>  256 threads = 4 waves, block tile (WM*TM*32) x (WN*TN*32): 128x128 for
+//                                   launches that do not fill the chip in whole rounds of the big tile, 64x64
+//                                   for batch-sized ones, 128x64 / 128x32 for the narrow tail layers; several
+//                                   workgroups per CU hide each other's stalls; also the k-major-operand
+//                                   (backward) instantiations;
+//   linear_fwd_pp2_kernel           512 threads, 256x128 tile, K % 32 == 0: the two waves of a SIMD alternate
+//                                   between "64 MFMAs" and "stage the next tile" (see there); 92 % of the fp32
+//                                   MFMA peak over the encoder's wide layers.
 // Common: K step 32.  Operand tiles go global -> registers -> LDS (the next tile's loads are issued
 // before the current tile's MFMAs).  LDS rows hold a 32-wide K slice with k de-interleaved inside
 // each group of 8 ([k0 k2 k4 k6 | k1 k3 k5 k7]) so that one ds_read_b128 per lane yields the lane's
-// operand for four consecutive MFMAs; rows are padded to 36 floats, which makes both the
-// ds_write_b128 and the ds_read_b128 pattern bank-conflict free (16 consecutive rows cover 16
-// distinct 4-bank slots; SQ_LDS_BANK_CONFLICT measures 0).
+// operand for four consecutive MFMAs; rows are padded to 36 floats, which makes the ds_read_b128
+// pattern bank-conflict free (16 consecutive rows cover 16 distinct 4-bank slots).
 #include "common.h"
 
 #include <stdlib.h>
 
 namespace lcrec {
-
-// LCREC_GEMM_TUNE bits other than bit 0 are timing-only ablations (they skip loads, stores or barriers
-// and produce wrong results); they exist only in builds made with -DLCREC_GEMM_ABLATE.
-#ifdef LCREC_GEMM_ABLATE
-#define LCREC_TUNE_MASK 0xff
-#else
-#define LCREC_TUNE_MASK 0x1
-#endif
 
 // In-kernel cycle stamps (diagnostic builds only: make STAMP=1, then lcrec_debug_gemm_stamps()).
 #ifdef LCREC_GEMM_STAMP
@@ -381,229 +376,26 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Ping-pong variant for the wide layers: 512 threads = 8 waves = two groups of 4; a block
-// computes a 256 x 128 tile, group g owning rows [128g, 128g+128).  The two waves that share a
-// SIMD belong to different groups and ALTERNATE roles every phase (one barrier per phase):
+// Ping-pong kernel for the wide layers (K % 32 == 0): 512 threads = 8 waves = two groups of 4; a workgroup
+// computes a 256 x 128 tile, group g owning rows [128g, 128g+128).  The two waves that share a SIMD belong
+// to different groups and ALTERNATE roles every phase (one barrier per phase):
 //
 //   phase 2u   : group 0 issues its global loads for K-tile u+1, then runs K-tile u's 64 MFMAs;
 //                group 1 writes the tile it loaded last phase (A1[u], upper half of W[u+1]) to LDS
 //   phase 2u+1 : group 1 loads (A1[u+1], upper W[u+2]) and runs K-tile u's MFMAs;
 //                group 0 writes (A0[u+1], lower half of W[u+1]) to LDS
 //
-// so each SIMD's MFMA pipe always has exactly one wave in its MFMA phase while its partner stages,
-// instead of co-resident workgroups drifting into the same phase (round 1: pipe idle 20 %).
-// A0/A1 need one LDS buffer each (a group reads and writes its own tile in different phases);
-// W is double-buffered because one group still reads W[u] while the other writes W[u+1].
-// Arithmetic is unchanged: one fma chain per output over k ascending.
-// ------------------------------------------------------------------------------------------
-template <int ROWS, int THREADS>
-struct StageRegsG {
-    static constexpr int ITERS = (ROWS * 4 + THREADS - 1) / THREADS;
-    f32x4 v[ITERS][2];
-    bool ok[ITERS];
-};
-
-template <int ROWS, int THREADS>
-__device__ __forceinline__ void stage_load_g(StageRegsG<ROWS, THREADS> &r, const float *__restrict__ src, int64_t row0,
-                                             int64_t rows_total, int K, int k0, int t)
-{
-#pragma unroll
-    for (int it = 0; it < StageRegsG<ROWS, THREADS>::ITERS; ++it) {
-        const int p = t + it * THREADS;
-        const int row = p >> 2, kg = p & 3;
-        const int64_t grow = row0 + row;
-        const int k = k0 + kg * 8;
-        // branch-free: out-of-range lanes read a clamped (valid) address; the zero is selected when the
-        // registers are written to LDS (stage_store_g), NOT here -- touching the loaded value now would
-        // put the s_waitcnt in front of the MFMAs this load is meant to hide behind
-        r.ok[it] = row < ROWS && grow < rows_total && k < K;
-        const int64_t crow = grow < rows_total ? grow : rows_total - 1;
-        const f32x4 *g = reinterpret_cast<const f32x4 *>(src + crow * (int64_t)K + (k < K ? k : 0));
-        r.v[it][0] = g[0];
-        r.v[it][1] = g[1];
-    }
-}
-
-template <int ROWS, int THREADS>
-__device__ __forceinline__ void stage_store_g(const StageRegsG<ROWS, THREADS> &r, float *lds, int t)
-{
-#pragma unroll
-    for (int it = 0; it < StageRegsG<ROWS, THREADS>::ITERS; ++it) {
-        const int p = t + it * THREADS;
-        const int row = p >> 2, kg = p & 3;
-        if (row < ROWS) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 a = r.ok[it] ? r.v[it][0] : z, b = r.ok[it] ? r.v[it][1] : z;
-            f32x4 ev = {a[0], a[2], b[0], b[2]};
-            f32x4 od = {a[1], a[3], b[1], b[3]};
-            f32x4 *d = reinterpret_cast<f32x4 *>(lds + row * LDK + kg * 8);
-            d[0] = ev;
-            d[1] = od;
-        }
-    }
-}
-
-__global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
-    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
-    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune)
-{
-    constexpr int GM = 128, BN = 128;           // rows per group, columns per block
-    __shared__ __attribute__((aligned(16))) float As[2][GM * LDK];
-    __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    // readfirstlane makes the wave index (hence the role branches and the s_setprio inside them, a scalar
-    // instruction that ignores EXEC) provably wave-uniform: real s_cbranch_scc branches, not exec masking
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
-    const int gt = tid & 255;
-
-    int64_t bm;
-    int bn;
-    if (tune & 1) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int panels = (bm_blocks - xcd + 7) >> 3;
-        if (j >= panels * bn_blocks) return;
-        bm = (int64_t)(j / bn_blocks) * 8 + xcd;
-        bn = j % bn_blocks;
-    } else {
-        bm = blockIdx.x / bn_blocks;
-        bn = blockIdx.x % bn_blocks;
-    }
-    const int64_t m0 = bm * (2 * GM) + grp * GM;   // this group's first row
-    const int n0 = bn * BN;
-    const int64_t w_row0 = n0 + grp * 64;          // the half of the W tile this group stages
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    StageRegsG<GM, 256> ra;     // this group's activation tile
-    StageRegsG<64, 256> rw;     // this group's half of the weight tile
-    const int nk = (K + BK - 1) / BK;
-    float *my_a = As[grp];
-
-    // ---- prologue: W[0] (both halves) and A0[0] into LDS; group 1 leaves (A1[0], upper W[1]) in registers
-    stage_load_g<64, 256>(rw, W, w_row0, N, K, 0, gt);
-    stage_store_g<64, 256>(rw, Ws[0] + grp * 64 * LDK, gt);
-    stage_load_g<GM, 256>(ra, A, m0, M, K, 0, gt);
-    if (grp == 0) {
-        stage_store_g<GM, 256>(ra, my_a, gt);
-    } else {
-        stage_load_g<64, 256>(rw, W, w_row0, N, K, BK, gt);      // upper W[1] (zeros if nk == 1)
-    }
-    __syncthreads();
-
-    const float *a_base = my_a + (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
-    const int w_off = (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
-
-    for (int u = 0; u < nk; ++u) {
-        const float *w_base = Ws[u & 1] + w_off;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (grp == half) {
-                // ---- compute role: K-tile u.  Fragment reads of the first half go out first (the partner
-                // wave on this SIMD is still issuing the second half of ITS tile, which hides their
-                // latency), then the global prefetch of the next tiles; the phase barrier sits after the
-                // LAST LDS read, so this wave's remaining 32 MFMAs overlap the partner's next phase.
-                LCREC_STAMP(0);
-                // Issue arbitration on a SIMD is priority, then age: a wave with back-to-back MFMAs queued
-                // starves its partner completely (measured with in-kernel stamps).  So every NON-MFMA stretch
-                // (fragment reads + global prefetch here, the LDS writes of the staging role) runs at raised
-                // priority and slips into the partner's MFMA stream, whose pipe stays busy 64 cycles per issue.
-                if (!(tune & 32)) __builtin_amdgcn_s_setprio(2);
-                f32x4 af[4][2], wf[4][2];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        af[g][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + g * 8);
-                        wf[g][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + g * 8);
-                    }
-                }
-                if (tune & (8 | 128)) {
-                } else if (half == 0) {
-                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A0[u+1]
-                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 1) * BK, gt);      // lower W[u+1]
-                } else {
-                    stage_load_g<GM, 256>(ra, A, m0, M, K, (u + 1) * BK, gt);          // A1[u+1]
-                    stage_load_g<64, 256>(rw, W, w_row0, N, K, (u + 2) * BK, gt);      // upper W[u+2]
-                }
-                if (!(tune & 32)) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (g == 1) {   // second half's fragments: issued under the first half's MFMAs
-#pragma unroll
-                        for (int gg = 2; gg < 4; ++gg) {
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                af[gg][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDK + gg * 8);
-                                wf[gg][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDK + gg * 8);
-                            }
-                        }
-                    }
-                    if (g == 2) {
-                        LCREC_STAMP(1);
-                        if (!(tune & 16)) __syncthreads();
-                        LCREC_STAMP(2);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][q], wf[g][j][q], acc[i][j], 0, 0, 0);
-                }
-                LCREC_STAMP(3);
-            } else {
-                // ---- staging role: registers loaded during this group's last compute phase -> LDS
-                LCREC_STAMP(0);
-                if (!(tune & 32)) __builtin_amdgcn_s_setprio(2);
-                if (tune & (8 | 64)) {
-                } else if (half == 0) {
-                    // group 1 in phase 2u: A1[u] (needed next phase) and the upper half of W[u+1]
-                    stage_store_g<GM, 256>(ra, my_a, gt);
-                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1] + 64 * LDK, gt);
-                } else {
-                    // group 0 in phase 2u+1: A0[u+1] and the lower half of W[u+1]
-                    stage_store_g<GM, 256>(ra, my_a, gt);
-                    stage_store_g<64, 256>(rw, Ws[(u + 1) & 1], gt);
-                }
-                LCREC_STAMP(1);
-                if (!(tune & 16)) __syncthreads();
-                LCREC_STAMP(2);
-                // stay at raised priority: the next thing this wave does is the compute role's fragment reads
-            }
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-
-    // epilogue: each wave transposes through 32 rows of its OWN group's activation buffer (its last
-    // LDS operand read is behind the final mid-phase barrier; the other group never touches it)
-    float *stg = my_a + w4 * 32 * LDK;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * 64 + i * 32, M, n0 + wn * 64 + j * 32, N, bias, bn_scale,
-                             bn_shift, relu);
-}
-
-// ------------------------------------------------------------------------------------------
-// Ping-pong kernel, second form, for K % 32 == 0 (every layer of the run.sh architecture).
-// Same tile, same roles, same phase barriers and the same arithmetic as linear_fwd_pp_kernel; what
-// changes is WHICH ISSUE PORT the non-MFMA work uses.  In-kernel cycle stamps (tools/stamp_probe.py)
-// showed that a wave with back-to-back fp32 MFMAs queued keeps the SIMD's VALU port: its partner's
-// VALU instructions get through about once per 64-cycle MFMA, so a staging role made of
-// 48 v_mov (the k de-interleave) + 12 ds_write_b128 took 2 400 cycles instead of ~200 and the computing
-// wave sat 500-700 cycles per phase at the barrier waiting for it.  LDS, vector-memory and scalar
-// instructions issue on their own ports and are not held up.  So here:
+// so each SIMD's MFMA pipe always has exactly one wave in its MFMA phase while its partner stages, instead of
+// co-resident workgroups drifting into the same phase.  A0/A1 need one LDS buffer each (a group reads and
+// writes its own tile in different phases); W is double-buffered because one group still reads W[u] while the
+// other writes W[u+1].  Arithmetic is unchanged: one fma chain per output over k ascending.
+//
+// Which ISSUE PORT the non-MFMA work uses decides whether this runs at the pipe's rate.  In-kernel cycle stamps
+// (tools/stamp_probe.py) showed that a wave with back-to-back fp32 MFMAs queued keeps the SIMD's VALU port: its
+// partner's VALU instructions get through about once per 64-cycle MFMA, so a staging role made of 48 v_mov (the
+// k de-interleave) + 12 ds_write_b128 + 64-bit address adds took 2 400 cycles instead of ~200 and the computing
+// wave sat 500-700 cycles per phase at the barrier waiting for it (first version of this kernel: 125 TFLOP/s).
+// LDS, vector-memory and scalar instructions issue on their own ports and are not held up.  So here:
 //   * the de-interleave is done by the LDS unit: ds_write2_b32 places any two registers at any two dword
 //     offsets, so (k0,k1) -> slots 0 and 4, (k2,k3) -> 1 and 5, ... : 24 LDS writes, zero VALU;
 //   * global loads are buffer loads: a scalar resource descriptor per tile (base = the tile's first row,
@@ -611,9 +403,9 @@ __global__ __launch_bounds__(512) void linear_fwd_pp_kernel(
 //     SGPR advanced by the scalar unit -- no VALU address arithmetic, and rows past M or N read as zero
 //     through the descriptor's range check instead of through compares and selects;
 //   * the K loop is unrolled by two so both W buffers are compile-time LDS offsets;
-//   * sched_barriers pin the second half's fragment reads under the first half's MFMAs.
+//   * sched_barriers pin each fragment refill right behind the MFMAs that free its registers;
+//   * after the mid-phase barrier the computing wave's remaining MFMAs run at raised priority (see there).
 // ------------------------------------------------------------------------------------------
-
 // Measured and rejected on MI355X (tools/gemm_probe.py, TFLOP/s on the 768->2048 / 2048->1024 layers; this form: 141 / 151):
 //   K slice of 64 per phase (half the barriers, 139 KB of LDS)                       133 / 144
 //   two workgroups per CU (register-capped to 128 VGPRs, 2 x 74 KB LDS)               137 / 140
@@ -842,24 +634,16 @@ static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float
 }
 
 static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *W, const float *b, const float *sc,
-                            const float *sh, int relu, int out_dim, float *y, int tune, hipStream_t stream)
+                            const float *sh, int relu, int out_dim, float *y, int xcd_order, hipStream_t stream)
 {
     const int64_t bm_blocks = (n + 255) / 256;
     const int bn_blocks = (out_dim + 127) / 128;
-    const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
+    const int64_t grid = xcd_order ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(K_LINEAR_PP, stream);
-    // K % 32 == 0 (and a tile's operand rows addressable with 31 bits): the VALU-free form
-    static const int pp2 = [] { const char *e = getenv("LCREC_GEMM_PP2"); return e ? atoi(e) : 1; }();   // 0: first form only
-    if (pp2 && in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31)) {
-        int rc = launch_pp2(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks,
-                            (int)bm_blocks, tune & 1);
-        if (rc) return rc;
-    }
-    else
-        hipLaunchKernelGGL(linear_fwd_pp_kernel, dim3((unsigned)grid), dim3(512), 0, stream, x, W, b, sc, sh, y, n,
-                           out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, tune);
-    return check_launch("linear_fwd_pp_kernel");
+    int rc = launch_pp2(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks,
+                        xcd_order);
+    return rc ? rc : check_launch("linear_fwd_pp2_kernel");
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -870,9 +654,8 @@ static int launch_linear(const float *x, int64_t n, int in_dim, const float *W, 
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     const int64_t bm_blocks = (n + BM - 1) / BM;
     const int bn_blocks = (out_dim + BN - 1) / BN;
-    // bit 0 = XCD-aware tile order (default on: same speed, 2.3x less fabric traffic by FETCH_SIZE);
-    // the other bits are timing-only experiments and must stay 0 in production
-    static const int tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & LCREC_TUNE_MASK; }();
+    // LCREC_GEMM_TUNE=0 turns the XCD-aware tile order off (default on: same speed, 2.3x less fabric traffic by FETCH_SIZE)
+    static const int tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & 1; }();
     const int64_t grid = (tune & 1) ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(BM == 64 ? K_LINEAR_64x64 : BN == 128 ? K_LINEAR_128x128 : BN == 64 ? K_LINEAR_128x64 : K_LINEAR_128x32, stream);
@@ -1021,14 +804,13 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     // tiles: 76 vs 83).  Otherwise the 128 x 128 / 64 x 64 kernels (several workgroups per CU, finer tail).
     // LCREC_GEMM_PP=0/1 forces one or the other (tuning only).
     static const int pp = [] { const char *e = getenv("LCREC_GEMM_PP"); return e ? atoi(e) : -1; }();
-    static const int pp_tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & LCREC_TUNE_MASK; }();
+    static const int pp_tune = [] { const char *e = getenv("LCREC_GEMM_TUNE"); return (e ? atoi(e) : 1) & 1; }();
     const int64_t pp_tiles = ((n + 255) / 256) * ((out_dim + 127) / 128);
     const int64_t pp_rounds = (pp_tiles + 255) / 256;
     const bool pp_fits = pp_tiles >= 256 && (pp_rounds >= 8 || pp_tiles * 5 >= pp_rounds * 256 * 4);
-    const bool use_pp = out_dim > 64 && (pp == 1 || (pp == -1 && pp_fits));
-    if (use_pp) {
-        return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
-    }
+    const bool pp_ok = in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31);     // else the generic kernels
+    const bool use_pp = out_dim > 64 && pp_ok && (pp == 1 || (pp == -1 && pp_fits));
+    if (use_pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
     if (out_dim > 64) {
         // batch-sized problems (a training step has 1-2 k rows): 128 x 128 tiles would leave most CUs idle,
         // so launches with fewer than two tiles per CU use 64 x 64 tiles (4x the workgroups)

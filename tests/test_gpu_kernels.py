@@ -19,14 +19,14 @@ def _rs(seed):
     (4096, 2048, 1024, True, True),
     (77, 4096, 2048, True, False),
     (1, 8, 32, False, False),
-    # launches that fill the CUs in whole rounds of 256 x 128 tiles go to the ping-pong kernels:
-    (8192, 64, 2048, True, True),        # second form (K % 32 == 0), every tile interior
-    (16000, 32, 2000, True, False),      # second form, ragged: last row panel half empty, last column tile partial
-    (8192, 72, 2048, True, False),       # first form (K % 32 != 0)
-    (8192, 40, 2001, False, True),       # first form, odd width (scalar stores)
-    (8192, 256, 2048, True, True),       # persistent form when enabled: two tiles per workgroup, BatchNorm epilogue
-    (16000, 192, 2048, True, False),     # ... four tiles per workgroup, last row panel half empty
-    (8200, 384, 4096, False, False),     # ... 33 row panels over 8 XCDs (holes in the tile walk), no ReLU
+    # launches that fill the CUs in whole rounds of 256 x 128 tiles go to the ping-pong kernel (K % 32 == 0):
+    (8192, 64, 2048, True, True),        # every tile interior
+    (16000, 32, 2000, True, False),      # ragged: last row panel half empty, last column tile partial
+    (8192, 72, 2048, True, False),       # K % 32 != 0 at that size: generic kernel, guarded loads
+    (8192, 40, 2001, False, True),       # ... and an odd width (scalar stores)
+    (8192, 256, 2048, True, True),       # BatchNorm epilogue
+    (16000, 192, 2048, True, False),     # six K-tiles, last row panel half empty
+    (8200, 384, 4096, False, False),     # 33 row panels over 8 XCDs (holes in the XCD-aware tile order), no ReLU
 ])
 def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     rs = _rs(n + k + out)
@@ -44,7 +44,7 @@ def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     hip.ops.trace_enable(False)
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
-    assert ("linear_fwd_pp_256x128" in trace) == (n >= 8192), trace      # the intended kernel ran
+    assert ("linear_fwd_pp_256x128" in trace) == (n >= 8192 and k % 32 == 0), trace      # the intended kernel ran
 
 
 @pytest.mark.parametrize("n,k,out", [(2048, 768, 2048), (475, 128, 64), (1000, 64, 32), (300, 2048, 1024), (77, 32, 128),
