@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const int64_t m0 = bm * BM;
     const int n0 = bn * BN;
     // (Measured and dropped: static per-workgroup s_setprio levels cost 4 %, start-up staggering of
-    // co-resident workgroups changed nothing.)
+    // co-resident workgroups changed nothing, double-buffered LDS with one barrier per K-tile lost 5-10 % at
+    // Games-sized launches -- the second buffer costs a co-resident workgroup.)
 
     f32x16 acc[TM][TN];
 #pragma unroll
