@@ -65,6 +65,9 @@ def parse_args(argv=None):
     # additions
     parser.add_argument("--no_bn", action="store_true", help="force bn=False (the bool flag cannot)")
     parser.add_argument("--no_kmeans_init", action="store_true", help="force kmeans_init=False")
+    parser.add_argument("--strict_nan_check", action="store_true",
+                        help="raise 'Training loss is nan' before the offending step's backward (a host sync per step, the "
+                             "reference's timing) instead of one step later")
     parser.add_argument("--kmeans_impl", type=str, default="sklearn", choices=["sklearn", "device"],
                         help="sklearn = the reference's host KMeans call; device = k-means++/Lloyd in HBM")
     args = parser.parse_args(argv)

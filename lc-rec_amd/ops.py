@@ -206,11 +206,55 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
     _lib.check(rc, "lcrec_sinkhorn_assign")
     if G > 0 and int(np.diff(offs).max()) * K > 16384:
         # the one-launch solver for batch-sized problems poisons its output with -1 if its (bounded)
-        # grid barrier ever times out; turn that into an error here rather than training on garbage
-        if bool((out < 0).any()):
+        # grid barrier ever times out; turn that into an error rather than training on garbage --
+        # here and now, or (inside deferred_checks(), the trainer's epoch loop) when the block ends,
+        # so that a training step has no host synchronisation of its own
+        bad = (out < 0).any()
+        if _deferred is not None:
+            _deferred.append(("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "
+                              "set LCREC_SINKHORN_PERSISTENT=0 to use the multi-launch solver", bad))
+        elif bool(bad):
             raise _lib.LcrecError("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "
                                   "set LCREC_SINKHORN_PERSISTENT=0 to use the multi-launch solver")
     return out
+
+
+_deferred = None
+
+
+class deferred_checks:
+    """Context in which result checks that need a device->host read (the Sinkhorn poison flag) are
+    collected as device booleans and evaluated together at exit, or every `every` collected checks."""
+
+    def __init__(self, every=256):
+        self.every = every
+
+    def __enter__(self):
+        global _deferred
+        self._outer = _deferred
+        _deferred = []
+        return self
+
+    def flush(self):
+        global _deferred
+        pending, _deferred = _deferred, []
+        if pending and bool(torch.stack([b for _, b in pending]).any()):
+            for msg, b in pending:
+                if bool(b):
+                    raise _lib.LcrecError(msg)
+
+    def poll(self):
+        if _deferred is not None and len(_deferred) >= self.every:
+            self.flush()
+
+    def __exit__(self, exc_type, exc, tb):
+        global _deferred
+        try:
+            if exc_type is None:
+                self.flush()
+        finally:
+            _deferred = self._outer
+        return False
 
 
 def rq_apply_level(resid, codebook, idx, xq=None, want_sse=False):

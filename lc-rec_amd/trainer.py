@@ -145,30 +145,60 @@ class Trainer(object):
         if torch.isnan(loss):
             raise ValueError("Training loss is nan")
 
+    def _check_nan_async(self, loss):
+        """trainer.py:40-42's check without stalling the launch pipeline: the flag of step t is copied to pinned
+        host memory asynchronously and read when step t+1 gets here, so the ValueError is raised one step later
+        than the reference raises it (the epoch loop's exit checks the last step)."""
+        if self.device.type != "cuda" or getattr(self.args, "strict_nan_check", False):
+            return self._check_nan(loss)           # the reference's timing: raise before this step's backward
+        if getattr(self, "_nan_host", None) is None:
+            self._nan_host = torch.zeros((), dtype=torch.bool).pin_memory()
+            self._nan_event = torch.cuda.Event()
+            self._nan_pending = False
+        if self._nan_pending:
+            self._nan_event.synchronize()          # recorded a whole step ago: already complete
+            if bool(self._nan_host):
+                self._nan_pending = False
+                raise ValueError("Training loss is nan")
+        self._nan_host.copy_(torch.isnan(loss.detach()), non_blocking=True)
+        self._nan_event.record()
+        self._nan_pending = True
+
+    def _check_nan_drain(self):
+        if getattr(self, "_nan_pending", False):
+            self._nan_pending = False
+            self._nan_event.synchronize()
+            if bool(self._nan_host):
+                raise ValueError("Training loss is nan")
+
     def _train_epoch(self, train_data, epoch_idx):
         self.model.train()
         total_loss = torch.zeros((), dtype=torch.float64, device=self.device)
         total_recon = torch.zeros((), dtype=torch.float64, device=self.device)
         iter_data = tqdm(train_data, total=len(train_data), ncols=100, desc=set_color(f"Train {epoch_idx}", "pink"),
                          disable=not self._is_main())
-        for data in iter_data:
-            data = data.to(self.device)
-            self.optimizer.zero_grad()
-            if self.use_ema:
-                out, rq_loss, _ = self.model(data, use_ema=True)
-            else:
-                out, rq_loss, _ = self.model(data)
-            loss, loss_recon = self.model.compute_loss(out, rq_loss, xs=data)
-            self._check_nan(loss)
-            loss.backward()
-            if self.dist is not None:
-                self.dist.reduce_gradients(self.model, n_local=data.shape[0])
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
-            self.optimizer.step()
-            self.scheduler.step()
-            # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step
-            total_loss += loss.detach().double()
-            total_recon += loss_recon.detach().double()
+        # no host synchronisation inside a step: the launch queue stays a step ahead of the GPU
+        with ops.deferred_checks() as checks:
+            for data in iter_data:
+                data = data.to(self.device)
+                self.optimizer.zero_grad()
+                if self.use_ema:
+                    out, rq_loss, _ = self.model(data, use_ema=True)
+                else:
+                    out, rq_loss, _ = self.model(data)
+                loss, loss_recon = self.model.compute_loss(out, rq_loss, xs=data)
+                self._check_nan_async(loss)
+                loss.backward()
+                if self.dist is not None:
+                    self.dist.reduce_gradients(self.model, n_local=data.shape[0])
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+                self.optimizer.step()
+                self.scheduler.step()
+                # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step
+                total_loss += loss.detach().double()
+                total_recon += loss_recon.detach().double()
+                checks.poll()
+            self._check_nan_drain()
         return total_loss.item(), total_recon.item()
 
     @torch.no_grad()

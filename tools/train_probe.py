@@ -17,6 +17,35 @@ from lcrec_amd import ops  # noqa: E402
 from lcrec_amd.trainer import linear_schedule_with_warmup  # noqa: E402
 
 
+def trainer_probe(a):
+    import tempfile
+    from lcrec_amd import main as cli
+    from lcrec_amd.datasets import DeviceLoader
+    from lcrec_amd.trainer import Trainer
+    dev = "cuda:0"
+    n = a.batch * 16
+    with tempfile.TemporaryDirectory() as tmp:
+        argv = ["--data_path", "unused", "--ckpt_dir", tmp, "--device", dev, "--batch_size", str(a.batch), "--epochs", "4",
+                "--no_kmeans_init"] + ([] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else [])
+        args = cli.parse_args(argv)
+        cli.seed_everything(2024)
+        model = cli.build_model(args, a.in_dim)
+        data = torch.randn((n, a.in_dim), device=dev)
+        loader = DeviceLoader(data, a.batch, True, dev)
+        trainer = Trainer(args, model, len(loader))
+        trainer._train_epoch(loader, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        epochs = max(1, a.steps // len(loader))
+        for e in range(epochs):
+            trainer._train_epoch(loader, e + 1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = epochs * len(loader)
+        print(f"Trainer._train_epoch: in_dim {a.in_dim} batch {a.batch} bn {a.bn} strict_nan_check {a.strict}: {dt / steps * 1e3:.3f} ms/step, "
+              f"{a.batch * steps / dt:,.0f} items/s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--in_dim", type=int, default=768)
@@ -25,7 +54,12 @@ def main():
     ap.add_argument("--bn", action="store_true")
     ap.add_argument("--ema", action="store_true")
     ap.add_argument("--no_sk", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="with --trainer: the per-step NaN host sync of the reference")
+    ap.add_argument("--trainer", action="store_true",
+                    help="time lcrec_amd.trainer.Trainer._train_epoch itself (loader, NaN check, fused AdamW, schedule)")
     a = ap.parse_args()
+    if a.trainer:
+        return trainer_probe(a)
     dev = torch.device("cuda:0")
     torch.manual_seed(2024)
     model = lcrec_amd.RQVAE(in_dim=a.in_dim, num_emb_list=[256] * 4, e_dim=32, layers=[2048, 1024, 512, 256, 128, 64],
@@ -37,7 +71,7 @@ def main():
         for q in model.rq.vq_layers:
             q.embedding.weight.copy_(z[torch.randperm(a.batch, device=dev)[:256]] * 0.5)
     model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)      # what Trainer builds on a HIP device
     sched = linear_schedule_with_warmup(opt, 10, 10000)
 
     def step():
