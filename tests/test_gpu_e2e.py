@@ -120,3 +120,27 @@ def test_generate_reproduces_reference_index_json_bytes(hip, tmp_path):
     want = bytes(g["json_text"])
     got = open(out, "rb").read()
     assert got == want, "index.json differs from the reference's bytes"
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_nan_loss_is_reported_with_and_without_the_per_step_sync(hip, tmp_path, strict):
+    """trainer.py:40-42 raises ValueError('Training loss is nan').  The default trainer reads the flag back
+    asynchronously (one step late, or when the epoch loop drains); --strict_nan_check keeps the reference's
+    host sync per step.  Either way the epoch must not end silently -- also when the NaN is in the LAST batch."""
+    from lcrec_amd import main as cli
+    from lcrec_amd.datasets import DeviceLoader
+    from lcrec_amd.trainer import Trainer
+    argv = ["--data_path", "unused", "--ckpt_dir", str(tmp_path), "--device", "cuda:0", "--batch_size", "64", "--epochs", "2",
+            "--layers", "32", "--e_dim", "16", "--num_emb_list", "32", "32", "--sk_epsilons", "0.0", "0.003",
+            "--no_kmeans_init", "--no_bn"] + (["--strict_nan_check"] if strict else [])
+    args = cli.parse_args(argv)
+    cli.seed_everything(2024)
+    for bad_batch in (1, 3):                       # a middle batch, and the last one
+        model = cli.build_model(args, 64)
+        data = torch.randn((256, 64), device="cuda:0")
+        loader = DeviceLoader(data, 64, False, "cuda:0")
+        trainer = Trainer(args, model, len(loader))
+        trainer._train_epoch(loader, 0)            # a clean epoch passes
+        data[bad_batch * 64 + 5, 7] = float("nan")
+        with pytest.raises(ValueError, match="Training loss is nan"):
+            trainer._train_epoch(loader, 1)
