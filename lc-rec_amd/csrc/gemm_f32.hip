@@ -413,8 +413,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 //   fragment refills dealt out one ds_read per MFMA, or staggered between the waves   123-132 / 129-140
 //   persistent workgroups (one per CU walking 16-32 tiles, K-tile stream flat across tiles, second accumulator
 //   set so that bias/BN/ReLU and the stores of tile t run under tile t+1): bit-exact, but      133 / 141
-//   (the K loop itself got 8 % slower and ate the saved prologue/epilogue; the code is in the repository history:
-//   "Experiment: persistent ping-pong GEMM ...").  A control experiment -- THIS kernel's body in a loop over a static
+//   (the K loop itself got 5-8 % slower and ate the saved prologue/epilogue -- also with the descriptors precomputed
+//   per tile and with a single copy of the phase code, so it is neither scalar work in front of the prefetch nor
+//   instruction-cache pressure; stamps show every other barrier interval ~650 cycles long.  The code is in the
+//   repository history: "Experiment: persistent ping-pong GEMM ...").  A control experiment -- THIS kernel's body in a loop over a static
 //   list of tiles, 256 workgroups -- runs at exactly the speed of one workgroup per tile (138.4 / 147.2 either way):
 //   neither the hardware's workgroup turn-around nor static assignment costs anything measurable here.
 // What is left is per-tile: ~3.5 k cycles of prologue and ~10 k of epilogue (all 256 CUs store their 128 KB
