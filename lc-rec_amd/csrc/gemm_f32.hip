@@ -419,6 +419,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 //   repository history: "Experiment: persistent ping-pong GEMM ...").  A control experiment -- THIS kernel's body in a loop over a static
 //   list of tiles, 256 workgroups -- runs at exactly the speed of one workgroup per tile (138.4 / 147.2 either way):
 //   neither the hardware's workgroup turn-around nor static assignment costs anything measurable here.
+//   Also without effect: prefetching two K-tiles ahead instead of one (second register set), unrolling the K loop by
+//   four (the ~400-cycle barrier delay the stamps show once per loop iteration is an artefact of the stamp build).
 // What is left is per-tile: ~3.5 k cycles of prologue and ~10 k of epilogue (all 256 CUs store their 128 KB
 // tiles at the same moment) against 8 225 cycles per K-tile in the loop (ideal 8 192).
 __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(

@@ -43,6 +43,13 @@ def main():
             role = "C" if (p % 2) == (w // 4) else "S"
             return role + " " + " ".join(f"{int(t):7d}" for t in v[: (4 if role == "C" else 3)])
         print(f"{p:5d} | {fmt(0):38s} | {fmt(4)}")
+    # arrival of each computing wave at the mid-phase barrier, relative to the earliest of the four: who is late?
+    print("phase | computing group | arrival at the barrier, cycles after the first of the four waves | barrier exit - last arrival")
+    for p in range(8, 24):
+        g = p % 2
+        arr = s[4 * g:4 * g + 4, p, 1]
+        print(f"{p:5d} | group {g}         | " + " ".join(f"{int(a - arr.min()):6d}" for a in arr) +
+              f" | {int(s[4 * g, p, 2] - arr.max()):6d}")
     # per-phase durations for a computing wave: entry -> barrier wait start -> barrier exit -> last MFMA issued
     comp = []
     for w in (0, 4):
