@@ -34,6 +34,8 @@ WORKLOADS = {
     "c3": dict(items=1_000_000, in_dim=768, name="C3 synthetic 1M x 768-d, 4x256 codes"),
     "c4": dict(items=1_250_000, in_dim=4096, name="C4 synthetic 10M x 4096-d over 8 GPUs (1.25M per GPU), 4x256 codes"),
     "c2": dict(items=16_859, in_dim=4096, name="C2 Games-sized 16859 x 4096-d, 4x256 codes"),
+    "c5": dict(items=1_250_000, in_dim=4096, codes=[1024] * 8,
+               name="C5 synthetic 10M x 4096-d over 8 GPUs (1.25M per GPU), 8x1024 codes (encode+assign pass)"),
 }
 HIDDEN = [2048, 1024, 512, 256, 128, 64]   # index/run.sh:15
 E_DIM = 32                                  # index/run.sh:10
@@ -42,7 +44,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md, chip-level pa
 PEAK_HBM_GBPS = 8000.0
 
 
-def synth_model(in_dim, device, seed=2024):
+def synth_model(in_dim, device, seed=2024, codes=None):
     """Random-init encoder in the reference's init (xavier_normal_ weights, zero bias;
     layers.py:33-40) and data-scale codebooks (rows sampled from each level's residuals,
     the stand-in for k-means named in SURVEY.md section 8d)."""
@@ -60,7 +62,7 @@ def synth_model(in_dim, device, seed=2024):
     for l in range(len(Ws)):
         z = lcrec_amd.ops.linear_forward(z, Ws[l], bs[l], relu=l != len(Ws) - 1)
     cbs, resid = [], z
-    for K in CODES:
+    for K in (codes or CODES):
         pick = torch.randperm(resid.shape[0], generator=g, device=device)[:K]
         cbs.append(resid[pick].clone())
         flat, ks = lcrec_amd.ops.flatten_codebooks(cbs)
@@ -107,7 +109,8 @@ def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=12.0):
     """The reference's CPU path (torch CPU ops of rqvae.py:68-72, restated in oracle/torch_ref.py),
     batch 4096, timed on this host's cores on a bounded sample."""
     from oracle import torch_ref
-    spec = torch_ref.Spec(dims[0], CODES, dims[-1], dims[1:-1], sk_epsilons=[0.0] * len(CODES))
+    codes = [int(c.shape[0]) for c in cbs]
+    spec = torch_ref.Spec(dims[0], codes, dims[-1], dims[1:-1], sk_epsilons=[0.0] * len(codes))
     sd = {}
     for l, (W, b) in enumerate(zip(Ws, bs)):
         slot = torch_ref.linear_slot(l, False)
@@ -172,7 +175,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     n = args.items or wl["items"]
-    dims, Ws, bs, cbs = synth_model(wl["in_dim"], device)
+    dims, Ws, bs, cbs = synth_model(wl["in_dim"], device, codes=wl.get("codes"))
     flat, ks = ops.flatten_codebooks(cbs)
     g = torch.Generator(device=device)
     g.manual_seed(2024 + rank)
@@ -249,7 +252,7 @@ def main():
         total_items = n * world * args.steps
         value = total_items / elapsed
         out = {
-            "metric": "item-embeddings/sec through 4-level RQ encode+assign", "value": value, "unit": "items/s",
+            "metric": f"item-embeddings/sec through {len(ks)}-level RQ encode+assign", "value": value, "unit": "items/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
