@@ -116,3 +116,25 @@ def test_sinkhorn_ragged_groups_with_empty_and_singleton(hip):
         Q = torch_ref.sinkhorn(torch_ref.centre_distances(d).double(), 0.003, 50)
         assert np.array_equal(out[lo:hi], torch.argmax(Q, -1).numpy()), g
     assert out[0] == 0
+
+
+def test_collision_groups_property_random_shapes(hip):
+    """lcrec_collision_groups against the reference's Python helpers (generate_indices.py:18-42) on many small
+    random index matrices: level counts 1..8, code ranges 1..1024 (mixed per level), heavy and zero duplication."""
+    from lcrec_amd import generate_indices as gen
+    rs = np.random.RandomState(123)
+    for trial in range(60):
+        L = int(rs.randint(1, 9))
+        Ks = [int(k) for k in rs.choice([1, 2, 3, 7, 16, 100, 256, 1024], size=L)]
+        n = int(rs.choice([1, 2, 3, 17, 64, 257, 1000]))
+        span = [max(1, int(k * rs.choice([1.0, 0.5, 0.05]))) for k in Ks]          # smaller span = more collisions
+        rows = np.stack([rs.randint(0, s, size=n) for s in span], axis=1).astype(np.int64)
+        keys = [tuple(r) for r in rows.tolist()]
+        got = hip.ops.collision_groups(torch.from_numpy(rows).to("cuda:0"), Ks, want_groups=True)
+        want = gen.get_collision_item(keys)
+        counts = gen.get_indices_count(keys)
+        assert got["groups"] == want, (trial, L, Ks, n)
+        assert got["unique"] == len(counts) and got["max_count"] == max(counts.values())
+        dev = hip.ops.collision_groups(torch.from_numpy(rows).to("cuda:0"), Ks, want_groups="device")
+        offs, mem = dev["offsets"].tolist(), dev["members"].tolist()
+        assert [mem[offs[g]:offs[g + 1]] for g in range(dev["n_groups"])] == want

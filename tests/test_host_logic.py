@@ -60,6 +60,16 @@ def test_library_argument_errors_are_reported_not_crashed():
     assert rc == -2 and b"e_dim=24" in lib.lcrec_last_error()
     rc = lib.lcrec_linear_forward(p, 2, 12, p, None, None, None, 0, 16, p, None)
     assert rc == -2 and b"multiple of 8" in lib.lcrec_last_error()
+    # backward products: shape rules, workspace contract, and the split count is a pure function of the sizes
+    assert lib.lcrec_linear_backward(None, p, p, 4, 8, 32, p, p, None, 0, None) == -1
+    assert lib.lcrec_linear_backward(p, p, p, 4, 8, 48, p, None, None, 0, None) == -2 and b"multiple of 32" in lib.lcrec_last_error()
+    assert lib.lcrec_linear_backward(p, p, p, 4, 6, 32, None, p, None, 0, None) == -2 and b"multiples of 4" in lib.lcrec_last_error()
+    assert lib.lcrec_linear_backward_splits(2048, 768, 2048) == 1          # wide layer: enough tiles already
+    s_narrow = lib.lcrec_linear_backward_splits(2048, 64, 32)
+    assert 2 <= s_narrow <= 16 and lib.lcrec_linear_backward_workspace(2048, 64, 32) == s_narrow * 64 * 32 * 4
+    assert lib.lcrec_linear_backward_splits(64, 64, 32) == 1               # too few K-tiles to split
+    assert lib.lcrec_linear_backward(p, p, p, 2048, 64, 32, None, p, None, 0, None) == -3 and b"workspace" in lib.lcrec_last_error()
+    assert lib.lcrec_linear_backward(p, p, p, 0, 64, 32, p, p, None, 0, None) == 0        # empty batch
 
 
 # ------------------------------------------------------------------ module tree / state dict
