@@ -20,7 +20,9 @@
  *     the calling thread's last error is lcrec_last_error(); nothing throws;
  *   - arithmetic contract: every contraction is one fp32 fused-multiply-add
  *     chain over k ascending starting at 0 (v_mfma_f32_32x32x2_f32 semantics);
- *     results are bit-identical to oracle/lcrec_oracle.c.
+ *     results are bit-identical to oracle/lcrec_oracle.c.  One documented
+ *     exception: the weight gradient of lcrec_linear_backward is an ordered sum
+ *     of a few such chains over runs of the batch (see there).
  */
 #ifndef LCREC_H
 #define LCREC_H
