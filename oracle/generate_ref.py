@@ -45,3 +45,17 @@ def run(x, weights, biases, codebooks, bn_scale=None, bn_shift=None, last_eps=0.
             idx[g, L - 1] = torch.argmax(Q, dim=-1).numpy()
     tokens = {i: [PREFIX[l].format(int(v)) for l, v in enumerate(row)] for i, row in enumerate(idx.tolist())}
     return idx, history, json.dumps(tokens)
+
+
+def reader_views(index):
+    """What the downstream stage derives from a loaded `.index.json` (reference data.py:38-89, BaseDataset):
+    get_new_tokens() = sorted set of all token strings (:43-54), get_all_items() = set of "".join(tokens)
+    per item (:56-66), and the per-position token sets behind get_prefix_allowed_tokens_fn (:68-79, before
+    tokenisation).  `index` is the dict json.load returns."""
+    new_tokens = sorted({tok for toks in index.values() for tok in toks})
+    all_items = {"".join(toks) for toks in index.values()}
+    allowed = {}
+    for toks in index.values():
+        for i, tok in enumerate(toks):
+            allowed.setdefault(i, set()).add(tok)
+    return new_tokens, all_items, allowed

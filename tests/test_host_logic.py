@@ -251,6 +251,18 @@ def test_index_json_is_what_the_downstream_reader_expects(tmp_path):
     new_tokens = sorted({t for toks in index.values() for t in toks})
     assert all(re.fullmatch(r"<[a-d]_\d+>", t) for t in new_tokens)
     assert gen.tokens_for([[1] * 8])[0][5:] == ["<f_1>", "<g_1>", "<h_1>"]          # beyond the reference's 5 prefixes
+    # the consumer's three views (data.py:43-79) of the reference's own F6 output and of ours are the same objects
+    from oracle import generate_ref
+    g = np.load(os.path.join(GOLD, "f6_generate.npz"))
+    ref_index = json.loads(bytes(g["json_text"]).decode())
+    path2 = str(tmp_path / "f6.index.json")
+    gen.dump_index_json(g["idx"].astype(np.int64), path2)
+    ours = json.load(open(path2))
+    assert generate_ref.reader_views(ours) == generate_ref.reader_views(ref_index)
+    new_tokens, all_items, allowed = generate_ref.reader_views(ours)
+    n_unique = len({tuple(r) for r in g["idx"].tolist()})
+    assert len(all_items) == n_unique and sorted(allowed) == list(range(g["idx"].shape[1]))
+    assert all(tok.startswith("<%s_" % "abcde"[i]) for i, toks in allowed.items() for tok in toks)
 
 
 def test_native_index_json_text_equals_json_dump():
