@@ -67,11 +67,14 @@ class DistContext:
             return rows
         counts = self._row_counts(rows.shape[0], rows.device)
         width = max(counts)
-        pad = torch.zeros((width,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        # gloo (the CPU rehearsal backend) has no all_gather for device tensors: stage through the host there
+        via_host = rows.is_cuda and tdist.get_backend() == "gloo"
+        work = torch.device("cpu") if via_host else rows.device
+        pad = torch.zeros((width,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=work)
         pad[:rows.shape[0]] = rows
         out = [torch.empty_like(pad) for _ in range(self.world_size)]
         tdist.all_gather(out, pad)
-        return torch.cat([o[:c] for o, c in zip(out, counts)])
+        return torch.cat([o[:c] for o, c in zip(out, counts)]).to(rows.device)
 
     def gather_rows_with_slice(self, rows):
         """(all rows in rank order, (lo, hi) of this rank's rows inside them)."""
@@ -81,6 +84,16 @@ class DistContext:
         allrows = self.gather_rows(rows)
         lo = sum(counts[:self.rank])
         return allrows, (lo, lo + counts[self.rank])
+
+    def global_means(self, values, n_local):
+        """Means over the GLOBAL batch of per-rank means `values` (a 1-d tensor) taken over n_local items each --
+        the loss scalars the trainer logs."""
+        if not self.enabled:
+            return values
+        w = float(n_local)
+        flat = torch.cat([values.detach().double() * w, torch.tensor([w], dtype=torch.float64, device=values.device)])
+        tdist.all_reduce(flat, op=tdist.ReduceOp.SUM)
+        return flat[:-1] / flat[-1]
 
     def all_reduce_sum_(self, *tensors):
         if not self.enabled:

@@ -37,16 +37,18 @@ class _LinearAct(torch.autograd.Function):
             gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
         gx = gw = gb = None
         out_dim, in_dim = weight.shape
-        if out_dim % 32 == 0 and in_dim % 4 == 0:
-            # both products read gy, x and W as they are stored (k-major operand staging in the kernel)
-            gx, gw = ops.linear_backward(gy, x, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        else:
-            if ctx.needs_input_grad[0]:
-                gx = ops.linear_forward(gy, weight.t().contiguous())          # [n,out] x [out,in]
-            if ctx.needs_input_grad[1]:
-                gw = ops.linear_forward(gy.t().contiguous(), x.t().contiguous())  # [out,n] x [n,in]
         if ctx.needs_input_grad[2]:
             gb = gy.sum(0)
+        # both products read gy, x and W as they are stored (k-major operand staging in the kernel), for any
+        # batch size.  A narrow layer whose width is not a multiple of the K slice (e_dim 16, say) is padded
+        # with zero columns / rows first: fma(0, w, acc) adds nothing, and the copies are a few KB.
+        pad = (-out_dim) % 32
+        if pad:
+            gy = F.pad(gy, (0, pad))
+            weight = F.pad(weight, (0, 0, 0, pad))
+        gx, gw = ops.linear_backward(gy, x, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        if pad and gw is not None:
+            gw = gw[:out_dim]
         return gx, gw, gb, None
 
 

@@ -194,9 +194,15 @@ class Trainer(object):
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
                 self.optimizer.step()
                 self.scheduler.step()
-                # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step
-                total_loss += loss.detach().double()
-                total_recon += loss_recon.detach().double()
+                # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step;
+                # data parallel: the loss of the global batch, not of this rank's slice
+                if self.dist is not None:
+                    both = self.dist.global_means(torch.stack([loss.detach(), loss_recon.detach()]), data.shape[0])
+                    total_loss += both[0]
+                    total_recon += both[1]
+                else:
+                    total_loss += loss.detach().double()
+                    total_recon += loss_recon.detach().double()
                 checks.poll()
             self._check_nan_drain()
         return total_loss.item(), total_recon.item()

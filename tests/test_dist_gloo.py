@@ -42,6 +42,10 @@ def _worker(rank, world, port, tmp):
     for p, q in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)
 
+    # ---- logged losses are global-batch means
+    means = ctx.global_means(torch.tensor([2.0 if rank == 0 else 4.0, 1.0]), n_local=hi - lo)
+    assert torch.allclose(means, torch.tensor([(2.0 * 7 + 4.0 * 4) / 11, 1.0], dtype=torch.float64))
+
     # ---- row gathers keep rank order with unequal counts
     rows = torch.arange((3 if rank == 0 else 5) * 2, dtype=torch.int64).view(-1, 2) + 100 * rank
     allrows = ctx.gather_rows(rows)

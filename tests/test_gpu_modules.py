@@ -156,3 +156,28 @@ def test_device_kmeans_matches_oracle_lloyd_and_is_reproducible(hip):
         assert torch.equal(a, b) and a.shape == (16, 32)
     finally:
         layers.KMEANS_IMPL = "sklearn"
+
+
+@pytest.mark.parametrize("batch", [13, 100, 475])
+def test_ragged_batches_train_and_match_the_reference_ops(hip, batch):
+    """The last batch of an epoch is whatever is left (Games: 16 859 % 1024 = 475 rows).  One training step on
+    batches that are not multiples of 8 / 32, with the e_dim-16 layer (narrower than a K slice): forward values
+    and every parameter gradient against the reference's op sequence on CPU (oracle/torch_ref + autograd)."""
+    from oracle import torch_ref
+    g, model, _ = _tiny(hip, 0)
+    x = torch.from_numpy(gi.f32(gi.rs(900 + batch).standard_normal((batch, 128))))
+    spec = torch_ref.Spec(128, [256] * 4, 16, [64, 32], bn=False, sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+    leaf = {k[4:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd__")}
+    leaf = {k: (v.requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in leaf.items()}
+    out_ref, rq_ref, idx_ref = torch_ref.forward(spec, leaf, x, use_sk=True, training=True)
+    loss_ref, _ = torch_ref.compute_loss(spec, out_ref, rq_ref, x)
+    loss_ref.backward()
+    model.train()
+    out, rq_loss, idx = model(x.to(DEV))
+    loss, _ = model.compute_loss(out, rq_loss, xs=x.to(DEV))
+    loss.backward()
+    assert np.array_equal(idx.cpu().numpy()[:, :3], idx_ref.numpy()[:, :3])          # argmin levels: exact
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=2e-5)
+    gmax = max(float(v.grad.abs().max()) for v in leaf.values() if v.requires_grad and v.grad is not None)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), leaf[k].grad.numpy(), rtol=2e-4, atol=2e-6 * gmax, err_msg=k)
