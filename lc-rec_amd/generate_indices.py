@@ -23,7 +23,6 @@ Documented divergences from the reference script:
 """
 import argparse
 import collections
-import json
 import logging
 import os
 

@@ -11,7 +11,6 @@ non-empty value -- including the `--bn False` in index/run.sh:9 -- parses as Tru
 """
 import argparse
 import logging
-import os
 import random
 
 import numpy as np

@@ -15,7 +15,6 @@ recorded in tests/golden/manifest.json:
 """
 import argparse
 import contextlib
-import copy
 import hashlib
 import io
 import json
