@@ -411,14 +411,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 //   K slice of 64 per phase (half the barriers, 139 KB of LDS)                       133 / 144
 //   two workgroups per CU (register-capped to 128 VGPRs, 2 x 74 KB LDS)               137 / 140
 //   fragment refills dealt out one ds_read per MFMA, or staggered between the waves   123-132 / 129-140
-//   persistent workgroups (one per CU walking 16-32 tiles, K-tile stream flat across tiles, second accumulator
-//   set so that bias/BN/ReLU and the stores of tile t run under tile t+1): bit-exact, but      133 / 141
-//   (the K loop itself got 5-8 % slower and ate the saved prologue/epilogue -- also with the descriptors precomputed
-//   per tile and with a single copy of the phase code, so it is neither scalar work in front of the prefetch nor
-//   instruction-cache pressure; stamps show every other barrier interval ~650 cycles long.  The code is in the
-//   repository history: "Experiment: persistent ping-pong GEMM ...").  A control experiment -- THIS kernel's body in a loop over a static
-//   list of tiles, 256 workgroups -- runs at exactly the speed of one workgroup per tile (138.4 / 147.2 either way):
-//   neither the hardware's workgroup turn-around nor static assignment costs anything measurable here.
+//   persistent workgroups with run-time decisions inside every phase (which descriptor, which epilogue piece):
+//   bit-exact, but the K loop lost 5-8 %.  The cause was found later (a uniform boolean materialised through a VGPR
+//   costs VALU instructions, which starve in the staging role) and the idea lives on as linear_fwd_pp3_kernel below,
+//   whose steady-state loop is this kernel's loop instruction for instruction.
+//   A control experiment -- THIS kernel's body in a loop over a static list of tiles, 256 workgroups -- runs at exactly
+//   the speed of one workgroup per tile: neither the hardware's workgroup turn-around nor static assignment costs
+//   anything measurable here.
 //   Also without effect: prefetching two K-tiles ahead instead of one (second register set), unrolling the K loop by
 //   four (the ~400-cycle barrier delay the stamps show once per loop iteration is an artefact of the stamp build).
 // What is left is per-tile: ~3.5 k cycles of prologue and ~10 k of epilogue (all 256 CUs store their 128 KB
@@ -627,6 +626,348 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
     LCREC_MARK(3);
 }
 
+// ------------------------------------------------------------------------------------------
+// Ping-pong kernel, persistent form (K % 64 == 0, K >= 384, N % 128 == 0): one workgroup per CU walks a list of
+// output tiles and never drains its pipeline between them.
+//   * The K-tile stream is flat across tiles: the last two K-tiles of a tile prefetch the first two of the next
+//     one (other buffer descriptors), so only the workgroup's first tile has a prologue.
+//   * A finished accumulator set moves to `prev` THROUGH the epilogue arithmetic (prev = relu(bn(acc + bias)) is the
+//     copy) in the wave's first COMPUTE phase of the next tile, where its own VALU work issues in the shadow of its
+//     own MFMAs; one 16 x 32 piece per STAGING phase of K-tiles 1..8 then goes through a wave-private LDS patch to
+//     16-byte buffer stores (LDS and vector-memory ports only; rows past M are dropped by the descriptor's range
+//     check).  The 128 KB per CU that linear_fwd_pp2_kernel stores in one burst at the end of every tile -- all 256
+//     CUs at the same instant -- drains under eight K-tiles of the next tile.
+//   * The K loop is split into HEAD (K-tiles 0..9, which carry the previous tile's epilogue), STEADY (exactly the
+//     phase code of linear_fwd_pp2_kernel: no extra branch, no extra scalar or vector instruction) and TAIL (the
+//     last two K-tiles, whose prefetch targets are static).  An earlier persistent form with run-time decisions
+//     inside every phase lost 5-8 % in the K loop: a uniform boolean that LLVM materialises through a VGPR costs two
+//     VALU instructions, and in the staging role those wait for gaps in the partner's MFMA stream.
+//   * Measured with per-wave stamps: a wave in the staging role is issued roughly one instruction per MFMA of its
+//     partner (~64 per phase, LDS / vector-memory / scalar alike), and in the steady state it reaches the barrier only
+//     ~100 cycles before the computing waves.  So the epilogue is cut into eight small pieces (14 instructions each);
+//     even so the piece phases run ~7 % longer than steady ones -- the remaining loss of this form.
+// Measured on MI355X (131 072 rows, TFLOP/s, this / linear_fwd_pp2_kernel): 768->2048 143 / 140, 2048->1024 151 / 150,
+// 1024->512 146 / 144, 512->256 138 / 134; C3 end to end 16.49 M vs 16.30 M items/s.
+// Same arithmetic as every other kernel here: one fma chain per output over k ascending, epilogue after it.
+// ------------------------------------------------------------------------------------------
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool HAS_BN>
+__global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
+    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int total_virtual, int xcd_order)
+{
+    constexpr int GM = 128, BN = 128, LDT = LDK;
+    // parts of a tile's K loop: HEAD0 = K-tile 0, HEAD_S0 + p = K-tile 1 + p carrying epilogue piece p (8 pieces: the
+    // two 16-row halves of the four 32 x 32 sub-tiles), STEADY, TAIL0 / TAIL1 = the last two K-tiles
+    constexpr int STEADY = 0, HEAD0 = 1, HEAD_S0 = 2, HEAD_S7 = 9, TAIL0 = 10, TAIL1 = 11;
+    extern __shared__ __attribute__((aligned(16))) float pp3_lds[];
+    float *As0 = pp3_lds;                        // [2][GM * LDT]
+    float *Ws0 = As0 + 2 * GM * LDT;             // [2][BN * LDT]
+    float *Ep0 = Ws0 + 2 * BN * LDT;             // [8][32 * LDT] wave-private transpose patches
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int gt = tid & 255;
+    const int nk = K / BK;
+    float *my_a = As0 + grp * GM * LDT;
+    float *patch = Ep0 + wave * 32 * LDT;
+
+    // tile walker: (m0 = first row of this GROUP's 128-row half, n0 = first column, valid row counts) as plain scalars
+    auto tile_of = [&](int t, int64_t &o_m0, int &o_n0, int &o_arows, int &o_wrows) __attribute__((always_inline)) -> bool {
+        int64_t bm;
+        int bn;
+        if (xcd_order) {
+            const int xcd = t & 7, j = t >> 3;
+            const int panels = (bm_blocks - xcd + 7) >> 3;
+            if (j >= panels * bn_blocks) return false;
+            bm = (int64_t)(j / bn_blocks) * 8 + xcd;
+            bn = j % bn_blocks;
+        } else {
+            if (t >= bm_blocks * bn_blocks) return false;
+            bm = t / bn_blocks;
+            bn = t % bn_blocks;
+        }
+        o_m0 = bm * (2 * GM) + grp * GM;
+        o_n0 = bn * BN;
+        const int64_t ar = M - o_m0, wr = (int64_t)N - (o_n0 + grp * 64);
+        o_arows = __builtin_amdgcn_readfirstlane((int)(ar < 0 ? 0 : (ar > GM ? GM : ar)));
+        o_wrows = __builtin_amdgcn_readfirstlane((int)(wr < 0 ? 0 : (wr > 64 ? 64 : wr)));
+        return true;
+    };
+    auto next_tile = [&](int t, int64_t &o_m0, int &o_n0, int &o_arows, int &o_wrows) __attribute__((always_inline)) -> int {
+        for (t += gridDim.x; t < total_virtual; t += gridDim.x)
+            if (tile_of(t, o_m0, o_n0, o_arows, o_wrows)) return t;
+        return total_virtual;
+    };
+
+    int64_t cur_m0 = 0, nxt_m0 = 0, prv_m0 = 0;
+    int cur_n0 = 0, nxt_n0 = 0, prv_n0 = 0, cur_ar = 0, nxt_ar = 0, prv_ar = 0, cur_wr = 0, nxt_wr = 0;
+    int t = blockIdx.x;
+    if (!tile_of(t, cur_m0, cur_n0, cur_ar, cur_wr)) t = next_tile(t, cur_m0, cur_n0, cur_ar, cur_wr);
+    if (t >= total_virtual) return;
+    int has_next = 0, have_prev = 0;
+
+    const int t_g = ((gt >> 2) * K + (gt & 3) * 8) * 4;
+    const int pass_g = 64 * K * 4;
+    const uint32_t t_s = (uint32_t)(((gt >> 2) * LDT + (gt & 3) * 8) * 4);
+    const uint32_t a_s0 = lds_addr(my_a) + t_s, a_s1 = a_s0 + 64 * LDT * 4;
+    const uint32_t w_s[2] = {lds_addr(Ws0 + grp * 64 * LDT) + t_s, lds_addr(Ws0 + BN * LDT + grp * 64 * LDT) + t_s};
+
+    // operand descriptors of the current and the next tile, rebuilt once per tile
+    __amdgpu_buffer_rsrc_t cur_a = tile_rsrc(A, cur_m0, M, GM, K), cur_w = tile_rsrc(W, cur_n0 + grp * 64, N, 64, K);
+    __amdgpu_buffer_rsrc_t nxt_a = cur_a, nxt_w = cur_w;
+
+    f32x4 ra[2][2], rw[2];
+    auto load_a = [&](__amdgpu_buffer_rsrc_t r, int kt) __attribute__((always_inline)) {
+        const int so = kt * (BK * 4);
+        ra[0][0] = buffer_load_f32x4(r, t_g, so);
+        ra[0][1] = buffer_load_f32x4(r, t_g + 16, so);
+        ra[1][0] = buffer_load_f32x4(r, t_g, so + pass_g);
+        ra[1][1] = buffer_load_f32x4(r, t_g + 16, so + pass_g);
+    };
+    auto load_w = [&](__amdgpu_buffer_rsrc_t r, int kt) __attribute__((always_inline)) {
+        const int so = kt * (BK * 4);
+        rw[0] = buffer_load_f32x4(r, t_g, so);
+        rw[1] = buffer_load_f32x4(r, t_g + 16, so);
+    };
+    auto store_a = [&]() __attribute__((always_inline)) {
+        lds_store_deint8(a_s0, ra[0][0], ra[0][1]);
+        lds_store_deint8(a_s1, ra[1][0], ra[1][1]);
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) { lds_store_deint8(w_s[buf], rw[0], rw[1]); };
+    auto lds_drain = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    // Workgroup barrier for LDS traffic only.  __syncthreads() is a release/acquire fence over ALL memory: with the
+    // previous tile's buffer stores in flight it waits for their completion (vmcnt(0), ~3 000 cycles per phase) although
+    // nothing in this kernel ever reads what another wave stored to global memory.
+    auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // per-column epilogue constants of a tile: this lane's two columns (j = 0, 1)
+    struct EpiConst { float b[2], sc[2], sh[2]; };
+    auto load_epi = [&](EpiConst &e, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            e.b[j] = bias ? bias[col] : 0.f;
+            e.sc[j] = HAS_BN ? bn_scale[col] : 1.f;
+            e.sh[j] = HAS_BN ? bn_shift[col] : 0.f;
+        }
+    };
+    auto epi_math = [&](f32x16 (&dst)[2][2], const f32x16 (&src)[2][2], const EpiConst &e) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = src[i][j][r] + e.b[j];
+                    if (HAS_BN) v = __builtin_fmaf(v, e.sc[j], e.sh[j]);
+                    if (relu) v = (v > 0.f) ? v : 0.f;
+                    dst[i][j][r] = v;
+                }
+    };
+    // one 32 x 32 sub-tile of a post-processed accumulator set -> C, through this wave's LDS patch
+    // The epilogue pieces run in the STAGING role, where every VALU instruction waits for a gap in the partner's MFMA
+    // stream: all addresses are computed once, here, and pinned in registers; the patch writes are ds_write_b32 with
+    // immediate offsets (written as asm so that they are not re-paired into ds_write2 with fresh base registers).
+    uint32_t patch_w = lds_addr(patch) + (uint32_t)((4 * (lane >> 5) * LDT + (lane & 31)) * 4);
+    uint32_t patch_r = lds_addr(patch) + (uint32_t)(((lane >> 3) * LDT + (lane & 7) * 4) * 4);
+    int c_voff = ((lane >> 3) * N + (lane & 7) * 4) * 4;
+    asm volatile("" : "+v"(patch_w), "+v"(patch_r), "+v"(c_voff));
+    // One piece = 16 rows x 32 columns (half hf of sub-tile (i, j)): 8 patch writes, 2 patch reads, 2 stores.  A wave in
+    // the staging role is issued roughly ONE instruction per MFMA of its partner -- LDS, vector-memory and scalar ones
+    // too, measured -- i.e. ~64 per phase, of which the operand staging takes ~20; a whole sub-tile (30 instructions)
+    // per phase made the staging role late for the barrier.
+    auto epi_store = [&](const f32x16 &v, auto i_c, auto j_c, auto hf_c, int64_t t_m0, int t_n0, int rows) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, hf = decltype(hf_c)::value;
+        const int extent = rows > 0 ? ((rows - 1) * N + BN) * 4 : 0;
+        const __amdgpu_buffer_rsrc_t c_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(C + t_m0 * (int64_t)N + t_n0, 0, extent, 0x00020000);
+#define LCREC_PATCH_W(R)                                                                                         \
+        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(patch_w), "v"(v[8 * hf + (R)]),                       \
+                     "n"((((R) & 3) + 8 * ((8 * hf + (R)) >> 2)) * LDT * 4) : "memory")
+        LCREC_PATCH_W(0); LCREC_PATCH_W(1); LCREC_PATCH_W(2); LCREC_PATCH_W(3);
+        LCREC_PATCH_W(4); LCREC_PATCH_W(5); LCREC_PATCH_W(6); LCREC_PATCH_W(7);
+#undef LCREC_PATCH_W
+        f32x4 q[2];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "ds_read_b128 %0, %2 offset:%3\n\t"
+                     "ds_read_b128 %1, %2 offset:%4\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(q[0]), "=&v"(q[1])
+                     : "v"(patch_r), "n"((2 * hf) * 8 * LDT * 4), "n"((2 * hf + 1) * 8 * LDT * 4)
+                     : "memory");
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int soff = ((wm * 64 + i * 32 + 8 * (2 * hf + p)) * N + wn * 64 + j * 32) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, q[p]), c_rsrc, c_voff, soff, 0);
+            // A 16-byte buffer store reads its data VGPRs a few cycles AFTER issue.  The compiler inserts the required
+            // wait state before an instruction that overwrites them -- except when the store has an SGPR offset (LLVM
+            // assumes that form is safe; on gfx950 it is not: the next VALU write, e.g. the v_cndmask of a branch
+            // condition, showed up as the value 1 in the first element of the stored vector).  So wait here.
+            asm volatile("s_nop 3" ::: "memory");
+        }
+    };
+
+    // ---- prologue of the workgroup's first tile: W[0] (both halves) and A0[0] into LDS; group 1 keeps (A1[0], upper W[1])
+    load_w(cur_w, 0);
+    store_w(0);
+    load_a(cur_a, 0);
+    if (grp == 0) {
+        store_a();
+    } else {
+        load_w(cur_w, 1);
+    }
+    lds_drain();
+    lds_barrier();
+
+    const float *a_base = my_a + (wm * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int w_off = (wn * 64 + (lane & 31)) * LDT + (lane >> 5) * 4;
+
+    f32x16 acc[2][2], prev[2][2];
+    EpiConst ec;
+    // one phase of K-tile u (PAR = u & 1 and half = which group computes, as constants; MODE = which part of the tile)
+    auto phase = [&](auto par_c, auto half_c, auto mode_c, int u) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value, half = decltype(half_c)::value, MODE = decltype(mode_c)::value;
+        if (grp == half) {
+            LCREC_STAMP(0);
+            const float *w_base = Ws0 + PAR * BN * LDT + w_off;
+            f32x4 af[2][2], wf[2][2];
+            auto frags = [&](int buf, int g) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[buf][i] = *reinterpret_cast<const f32x4 *>(a_base + i * 32 * LDT + g * 8);
+                    wf[buf][i] = *reinterpret_cast<const f32x4 *>(w_base + i * 32 * LDT + g * 8);
+                }
+            };
+            auto mfma_group = [&](const f32x4 (&a2)[2], const f32x4 (&w2)[2]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i][q], w2[j][q], acc[i][j], 0, 0, 0);
+            };
+            auto reads_then_mfmas = [&]() {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            };
+            if constexpr (MODE == HEAD0) {
+                // first K-tile of a tile: the previous tile's post-processing (with ITS constants), then this tile's
+                // constants and a zeroed accumulator set
+                if (have_prev) epi_math(prev, acc, ec);
+                load_epi(ec, cur_n0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            frags(0, 0);
+            frags(1, 1);
+            __builtin_amdgcn_sched_barrier(0);                          // fragment reads first: the MFMAs wait for them
+            if constexpr (MODE == TAIL0) {                              // u = nk - 2
+                if (half == 0) {
+                    load_a(cur_a, u + 1);
+                    load_w(cur_w, u + 1);
+                } else {
+                    load_a(cur_a, u + 1);
+                    if (has_next) load_w(nxt_w, 0);
+                }
+            } else if constexpr (MODE == TAIL1) {                       // u = nk - 1: the next tile's first K-tiles
+                if (has_next) {
+                    load_a(nxt_a, 0);
+                    load_w(nxt_w, half == 0 ? 0 : 1);
+                }
+            } else {
+                load_a(cur_a, u + 1);                                   // half 0: A0[u+1], lower W[u+1]
+                load_w(cur_w, half == 0 ? u + 1 : u + 2);               // half 1: A1[u+1], upper W[u+2]
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(af[0], wf[0]);                                   // k group 0
+            __builtin_amdgcn_sched_barrier(0);
+            frags(0, 2);
+            mfma_group(af[1], wf[1]);                                   // k group 1
+            reads_then_mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            frags(1, 3);
+            mfma_group(af[0], wf[0]);                                   // k group 2
+            reads_then_mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            LCREC_STAMP(1);
+            lds_barrier();                                            // after this wave's LAST LDS read of the tile
+            LCREC_STAMP(2);
+            __builtin_amdgcn_s_setprio(3);
+            mfma_group(af[1], wf[1]);                                   // k group 3
+            __builtin_amdgcn_s_setprio(0);
+            LCREC_STAMP(3);
+        } else {
+            LCREC_STAMP(0);
+            store_a();
+            store_w(PAR ^ 1);
+            lds_drain();
+            LCREC_STAMP(1);
+            // K-tiles 1..4 of a tile: one sub-tile of the previous tile's output per staging phase
+            if constexpr (MODE >= HEAD_S0 && MODE <= HEAD_S7) {
+                if (have_prev) {
+                    constexpr int s = (MODE - HEAD_S0) >> 1, hf = (MODE - HEAD_S0) & 1;
+                    epi_store(prev[s >> 1][s & 1], IntC<(s >> 1)>{}, IntC<(s & 1)>{}, IntC<hf>{}, prv_m0, prv_n0, prv_ar);
+                }
+            }
+            LCREC_STAMP(3);
+            lds_barrier();
+            LCREC_STAMP(2);
+        }
+    };
+    auto pair = [&](auto par_c, auto mode_c, int u) __attribute__((always_inline)) {
+        phase(par_c, IntC<0>{}, mode_c, u);
+        phase(par_c, IntC<1>{}, mode_c, u);
+    };
+    auto finish = [&]() __attribute__((always_inline)) {     // the workgroup's last tile: nothing left to hide behind
+        epi_math(acc, acc, ec);
+        epi_store(acc[0][0], IntC<0>{}, IntC<0>{}, IntC<0>{}, cur_m0, cur_n0, cur_ar);
+        epi_store(acc[0][0], IntC<0>{}, IntC<0>{}, IntC<1>{}, cur_m0, cur_n0, cur_ar);
+        epi_store(acc[0][1], IntC<0>{}, IntC<1>{}, IntC<0>{}, cur_m0, cur_n0, cur_ar);
+        epi_store(acc[0][1], IntC<0>{}, IntC<1>{}, IntC<1>{}, cur_m0, cur_n0, cur_ar);
+        epi_store(acc[1][0], IntC<1>{}, IntC<0>{}, IntC<0>{}, cur_m0, cur_n0, cur_ar);
+        epi_store(acc[1][0], IntC<1>{}, IntC<0>{}, IntC<1>{}, cur_m0, cur_n0, cur_ar);
+        epi_store(acc[1][1], IntC<1>{}, IntC<1>{}, IntC<0>{}, cur_m0, cur_n0, cur_ar);
+        epi_store(acc[1][1], IntC<1>{}, IntC<1>{}, IntC<1>{}, cur_m0, cur_n0, cur_ar);
+    };
+
+    for (;;) {
+        const int tn = next_tile(t, nxt_m0, nxt_n0, nxt_ar, nxt_wr);
+        has_next = tn < total_virtual ? 1 : 0;
+        pair(IntC<0>{}, IntC<HEAD0>{}, 0);
+        pair(IntC<1>{}, IntC<HEAD_S0 + 0>{}, 1);
+        pair(IntC<0>{}, IntC<HEAD_S0 + 1>{}, 2);
+        pair(IntC<1>{}, IntC<HEAD_S0 + 2>{}, 3);
+        pair(IntC<0>{}, IntC<HEAD_S0 + 3>{}, 4);
+        pair(IntC<1>{}, IntC<HEAD_S0 + 4>{}, 5);
+        pair(IntC<0>{}, IntC<HEAD_S0 + 5>{}, 6);
+        pair(IntC<1>{}, IntC<HEAD_S0 + 6>{}, 7);
+        pair(IntC<0>{}, IntC<HEAD_S0 + 7>{}, 8);
+        pair(IntC<1>{}, IntC<STEADY>{}, 9);
+        for (int u = 10; u < nk - 2; u += 2) {                  // the loop of linear_fwd_pp2_kernel, instruction for instruction
+            pair(IntC<0>{}, IntC<STEADY>{}, u);
+            pair(IntC<1>{}, IntC<STEADY>{}, u + 1);
+        }
+        nxt_a = tile_rsrc(A, nxt_m0, M, GM, K);                // built here, not at the tile's start: 8 SGPRs less in the loop
+        nxt_w = tile_rsrc(W, nxt_n0 + grp * 64, N, 64, K);
+        pair(IntC<0>{}, IntC<TAIL0>{}, nk - 2);
+        pair(IntC<1>{}, IntC<TAIL1>{}, nk - 1);
+        if (!has_next) { finish(); break; }
+        prv_m0 = cur_m0; prv_n0 = cur_n0; prv_ar = cur_ar;
+        cur_m0 = nxt_m0; cur_n0 = nxt_n0; cur_ar = nxt_ar; cur_wr = nxt_wr; cur_a = nxt_a; cur_w = nxt_w;
+        t = tn;
+        have_prev = 1;
+    }
+}
+
 static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float *W, const float *b, const float *sc,
                       const float *sh, float *y, int64_t n, int out_dim, int in_dim, int relu, int bn_blocks, int bm_blocks,
                       int xcd_order)
@@ -640,6 +981,32 @@ static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float
     return LCREC_OK;
 }
 
+static int launch_pp3(int total_virtual, hipStream_t stream, const float *x, const float *W, const float *b, const float *sc,
+                      const float *sh, float *y, int64_t n, int out_dim, int in_dim, int relu, int bn_blocks, int bm_blocks,
+                      int xcd_order)
+{
+    constexpr size_t lds = (size_t)(2 * 128 + 2 * 128 + 8 * 32) * LDK * sizeof(float);     // 110 592 B
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+        return v > 8 ? v / 8 * 8 : 8;                // a multiple of 8 keeps a workgroup's tiles on its own XCD
+    }();
+    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_fwd_pp3_kernel<false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_fwd_pp3_kernel<true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr0 != hipSuccess || attr1 != hipSuccess)
+        return fail(LCREC_EHIP, "linear_forward: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(attr0 != hipSuccess ? attr0 : attr1));
+    const int grid = total_virtual < cus ? total_virtual : cus;
+    if (sc)
+        hipLaunchKernelGGL(linear_fwd_pp3_kernel<true>, dim3((unsigned)grid), dim3(512), lds, stream, x, W, b, sc, sh, y, n, out_dim,
+                           in_dim, relu, bn_blocks, bm_blocks, total_virtual, xcd_order);
+    else
+        hipLaunchKernelGGL(linear_fwd_pp3_kernel<false>, dim3((unsigned)grid), dim3(512), lds, stream, x, W, b, sc, sh, y, n, out_dim,
+                           in_dim, relu, bn_blocks, bm_blocks, total_virtual, xcd_order);
+    return LCREC_OK;
+}
+
 static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *W, const float *b, const float *sc,
                             const float *sh, int relu, int out_dim, float *y, int xcd_order, hipStream_t stream)
 {
@@ -648,7 +1015,13 @@ static int launch_linear_pp(const float *x, int64_t n, int in_dim, const float *
     const int64_t grid = xcd_order ? ((bm_blocks + 7) / 8) * 8 * bn_blocks : bm_blocks * bn_blocks;
     if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear_forward: grid too large (n=%lld)", (long long)n);
     TraceScope trace(K_LINEAR_PP, stream);
-    int rc = launch_pp2(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks,
+    // the persistent form where it applies (measured +1.2 % on C3, +0.5 .. +3.4 % per layer); LCREC_GEMM_PP3=0 turns it off
+    static const int pp3 = [] { const char *e = getenv("LCREC_GEMM_PP3"); return e ? atoi(e) : 1; }();
+    int rc;
+    if (pp3 && in_dim % 64 == 0 && in_dim >= 12 * BK && out_dim % 128 == 0 && (int64_t)out_dim * 4 * 128 < (1ll << 31))
+        rc = launch_pp3((int)grid, stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks, xcd_order);
+    else
+        rc = launch_pp2(dim3((unsigned)grid), stream, x, W, b, sc, sh, y, n, out_dim, in_dim, relu, bn_blocks, (int)bm_blocks,
                         xcd_order);
     return rc ? rc : check_launch("linear_fwd_pp2_kernel");
 }

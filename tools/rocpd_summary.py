@@ -15,7 +15,7 @@ import json
 import sqlite3
 import sys
 
-NAMES = [("linear_fwd_pp2_kernel", "linear_fwd_pp_256x128"), ("linear_fwd_pp_kernel", "linear_fwd_pp_256x128"),
+NAMES = [("linear_fwd_pp3_kernel", "linear_fwd_pp_256x128"), ("linear_fwd_pp2_kernel", "linear_fwd_pp_256x128"), ("linear_fwd_pp_kernel", "linear_fwd_pp_256x128"),
          ("linear_fwd_kernel<2, 2, 2, 2", "linear_fwd_128x128"), ("linear_fwd_kernel<2, 2, 1, 1", "linear_fwd_64x64"),
          ("linear_fwd_kernel<4, 1, 1, 2", "linear_fwd_128x64"), ("linear_fwd_kernel<4, 1, 1, 1", "linear_fwd_128x32"),
          ("rq_assign_kernel", "rq_assign")]

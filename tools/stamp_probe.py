@@ -37,7 +37,7 @@ def main():
     s = np.frombuffer(buf, dtype=np.uint64).reshape(8, 64, 4).astype(np.int64)
     t0 = s[:, 8, 0].min()
     print("phase | wave0 (group 0)                       | wave4 (group 1)        [cycles since phase 8 entry]")
-    for p in range(8, 24):
+    for p in range(int(os.environ.get("PROBE_P0", "8")), 24):
         def fmt(w):
             v = s[w, p] - t0
             role = "C" if (p % 2) == (w // 4) else "S"
@@ -45,11 +45,13 @@ def main():
         print(f"{p:5d} | {fmt(0):38s} | {fmt(4)}")
     # arrival of each computing wave at the mid-phase barrier, relative to the earliest of the four: who is late?
     print("phase | computing group | arrival at the barrier, cycles after the first of the four waves | barrier exit - last arrival")
-    for p in range(8, 24):
+    for p in range(int(os.environ.get("PROBE_P0", "8")), 24):
         g = p % 2
         arr = s[4 * g:4 * g + 4, p, 1]
+        stg = s[4 * (1 - g):4 * (1 - g) + 4, p, 3]          # staging waves: just before their barrier (persistent form only)
+        late = f" | staging waves arrive {' '.join(f'{int(a - arr.max()):6d}' for a in stg)} after the last computing wave" if stg.any() else ""
         print(f"{p:5d} | group {g}         | " + " ".join(f"{int(a - arr.min()):6d}" for a in arr) +
-              f" | {int(s[4 * g, p, 2] - arr.max()):6d}")
+              f" | {int(s[4 * g, p, 2] - arr.max()):6d}" + late)
     # per-phase durations for a computing wave: entry -> barrier wait start -> barrier exit -> last MFMA issued
     comp = []
     for w in (0, 4):
