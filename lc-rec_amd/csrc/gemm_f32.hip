@@ -644,8 +644,8 @@ __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
 //     VALU instructions, and in the staging role those wait for gaps in the partner's MFMA stream.
 //   * Measured with per-wave stamps: a wave in the staging role is issued roughly one instruction per MFMA of its
 //     partner (~64 per phase, LDS / vector-memory / scalar alike), and in the steady state it reaches the barrier only
-//     ~100 cycles before the computing waves.  So the epilogue is cut into eight small pieces (14 instructions each);
-//     even so the piece phases run ~7 % longer than steady ones -- the remaining loss of this form.
+//     ~100 cycles before the computing waves.  So the epilogue is cut into eight pieces and each piece between the
+//     roles: patch writes in the compute role, two reads + two stores in the staging role.
 // Measured on MI355X (131 072 rows, TFLOP/s, this / linear_fwd_pp2_kernel): 768->2048 143 / 140, 2048->1024 151 / 150,
 // 1024->512 146 / 144, 512->256 138 / 134; C3 end to end 16.49 M vs 16.30 M items/s.
 // Same arithmetic as every other kernel here: one fma chain per output over k ascending, epilogue after it.
@@ -661,7 +661,8 @@ __global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
     constexpr int GM = 128, BN = 128, LDT = LDK;
     // parts of a tile's K loop: HEAD0 = K-tile 0, HEAD_S0 + p = K-tile 1 + p carrying epilogue piece p (8 pieces: the
     // two 16-row halves of the four 32 x 32 sub-tiles), STEADY, TAIL0 / TAIL1 = the last two K-tiles
-    constexpr int STEADY = 0, HEAD0 = 1, HEAD_S0 = 2, HEAD_S7 = 9, TAIL0 = 10, TAIL1 = 11;
+    // (HEAD_S0 + 8 = K-tile 9: group 1, whose staging phase precedes its compute phase in a K-tile, sends its last piece)
+    constexpr int STEADY = 0, HEAD0 = 1, HEAD_S0 = 2, HEAD_S8 = 10, TAIL0 = 11, TAIL1 = 12;
     extern __shared__ __attribute__((aligned(16))) float pp3_lds[];
     float *As0 = pp3_lds;                        // [2][GM * LDT]
     float *Ws0 = As0 + 2 * GM * LDT;             // [2][BN * LDT]
@@ -776,21 +777,26 @@ __global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
     uint32_t patch_r = lds_addr(patch) + (uint32_t)(((lane >> 3) * LDT + (lane & 7) * 4) * 4);
     int c_voff = ((lane >> 3) * N + (lane & 7) * 4) * 4;
     asm volatile("" : "+v"(patch_w), "+v"(patch_r), "+v"(c_voff));
-    // One piece = 16 rows x 32 columns (half hf of sub-tile (i, j)): 8 patch writes, 2 patch reads, 2 stores.  A wave in
-    // the staging role is issued roughly ONE instruction per MFMA of its partner -- LDS, vector-memory and scalar ones
-    // too, measured -- i.e. ~64 per phase, of which the operand staging takes ~20; a whole sub-tile (30 instructions)
-    // per phase made the staging role late for the barrier.
-    auto epi_store = [&](const f32x16 &v, auto i_c, auto j_c, auto hf_c, int64_t t_m0, int t_n0, int rows) __attribute__((always_inline)) {
-        constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, hf = decltype(hf_c)::value;
-        const int extent = rows > 0 ? ((rows - 1) * N + BN) * 4 : 0;
-        const __amdgpu_buffer_rsrc_t c_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(C + t_m0 * (int64_t)N + t_n0, 0, extent, 0x00020000);
+    // One piece = 16 rows x 32 columns (half hf of sub-tile (i, j)).  A wave in the staging role is issued roughly ONE
+    // instruction per MFMA of its partner -- LDS, vector-memory and scalar ones too, measured -- and is within ~100
+    // cycles of being the barrier's last arrival even in the steady state.  So a piece is split between the roles: its 8
+    // patch writes go out in the COMPUTE role (epi_patch: LDS writes issue freely in the shadow of the wave's own MFMAs),
+    // and only 2 patch reads + 2 stores remain for the wave's next STAGING role (epi_send).
+    auto epi_patch = [&](const f32x16 &v, auto hf_c) __attribute__((always_inline)) {
+        constexpr int hf = decltype(hf_c)::value;
+        const uint32_t pw = patch_w;          // (named here: an implicit capture inside a dependent asm operand is not seen)
 #define LCREC_PATCH_W(R)                                                                                         \
-        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(patch_w), "v"(v[8 * hf + (R)]),                       \
+        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(pw), "v"(v[8 * hf + (R)]),                            \
                      "n"((((R) & 3) + 8 * ((8 * hf + (R)) >> 2)) * LDT * 4) : "memory")
         LCREC_PATCH_W(0); LCREC_PATCH_W(1); LCREC_PATCH_W(2); LCREC_PATCH_W(3);
         LCREC_PATCH_W(4); LCREC_PATCH_W(5); LCREC_PATCH_W(6); LCREC_PATCH_W(7);
 #undef LCREC_PATCH_W
+    };
+    auto epi_send = [&](auto i_c, auto j_c, auto hf_c, int64_t t_m0, int t_n0, int rows) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, hf = decltype(hf_c)::value;
+        const int extent = rows > 0 ? ((rows - 1) * N + BN) * 4 : 0;
+        const __amdgpu_buffer_rsrc_t c_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(C + t_m0 * (int64_t)N + t_n0, 0, extent, 0x00020000);
         f32x4 q[2];
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      "ds_read_b128 %0, %2 offset:%3\n\t"
@@ -809,6 +815,10 @@ __global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
             // condition, showed up as the value 1 in the first element of the stored vector).  So wait here.
             asm volatile("s_nop 3" ::: "memory");
         }
+    };
+    auto epi_store = [&](const f32x16 &v, auto i_c, auto j_c, auto hf_c, int64_t t_m0, int t_n0, int rows) __attribute__((always_inline)) {
+        epi_patch(v, hf_c);
+        epi_send(i_c, j_c, hf_c, t_m0, t_n0, rows);
     };
 
     // ---- prologue of the workgroup's first tile: W[0] (both halves) and A0[0] into LDS; group 1 keeps (A1[0], upper W[1])
@@ -890,6 +900,13 @@ __global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(af[0], wf[0]);                                   // k group 0
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MODE >= HEAD_S0 && MODE < HEAD_S8) {          // this K-tile's epilogue piece into the patch
+                if (have_prev) {
+                    constexpr int s = (MODE - HEAD_S0) >> 1, hf = (MODE - HEAD_S0) & 1;
+                    epi_patch(prev[s >> 1][s & 1], IntC<hf>{});
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             frags(0, 2);
             mfma_group(af[1], wf[1]);                                   // k group 1
             reads_then_mfmas();
@@ -912,10 +929,13 @@ __global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
             lds_drain();
             LCREC_STAMP(1);
             // K-tiles 1..4 of a tile: one sub-tile of the previous tile's output per staging phase
-            if constexpr (MODE >= HEAD_S0 && MODE <= HEAD_S7) {
+            // the piece this wave wrote to its patch in its last compute phase: this K-tile's for group 0 (half == 1
+            // phases), the previous K-tile's for group 1 (whose staging phase comes first in a K-tile)
+            constexpr int PIECE = MODE - HEAD_S0 - (half == 0 ? 1 : 0);
+            if constexpr (MODE >= HEAD_S0 && MODE <= HEAD_S8 && PIECE >= 0 && PIECE < 8) {
                 if (have_prev) {
-                    constexpr int s = (MODE - HEAD_S0) >> 1, hf = (MODE - HEAD_S0) & 1;
-                    epi_store(prev[s >> 1][s & 1], IntC<(s >> 1)>{}, IntC<(s & 1)>{}, IntC<hf>{}, prv_m0, prv_n0, prv_ar);
+                    constexpr int s = PIECE >> 1, hf = PIECE & 1;
+                    epi_send(IntC<(s >> 1)>{}, IntC<(s & 1)>{}, IntC<hf>{}, prv_m0, prv_n0, prv_ar);
                 }
             }
             LCREC_STAMP(3);
@@ -951,7 +971,7 @@ __global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
         pair(IntC<0>{}, IntC<HEAD_S0 + 5>{}, 6);
         pair(IntC<1>{}, IntC<HEAD_S0 + 6>{}, 7);
         pair(IntC<0>{}, IntC<HEAD_S0 + 7>{}, 8);
-        pair(IntC<1>{}, IntC<STEADY>{}, 9);
+        pair(IntC<1>{}, IntC<HEAD_S8>{}, 9);
         for (int u = 10; u < nk - 2; u += 2) {                  // the loop of linear_fwd_pp2_kernel, instruction for instruction
             pair(IntC<0>{}, IntC<STEADY>{}, u);
             pair(IntC<1>{}, IntC<STEADY>{}, u + 1);
