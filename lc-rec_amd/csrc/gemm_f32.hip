@@ -422,6 +422,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 //   four (the ~400-cycle barrier delay the stamps show once per loop iteration is an artefact of the stamp build).
 //   Natural k order in LDS (6 ds_write_b128 in the staging role instead of 12 ds_write2_b32, but 2 ds_read2_b32 per
 //   fragment in the computing role instead of 1 ds_read_b128)                         133 / 141
+//   256 x 256 workgroup tile (each wave 64 x 128, 128 MFMAs per phase, 222 VGPRs)      142 / 150  (= the persistent form;
+//   the epilogue is proportional to the output, so a bigger tile amortises only the prologue)
 // What is left is per-tile: ~3.5 k cycles of prologue and ~10 k of epilogue (all 256 CUs store their 128 KB
 // tiles at the same moment) against 8 225 cycles per K-tile in the loop (ideal 8 192).
 __global__ __launch_bounds__(512) void linear_fwd_pp2_kernel(
