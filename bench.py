@@ -16,8 +16,11 @@ Workloads (BASELINE.json configs):
 Items shard across ranks with no data-path collective (weak scaling: fixed items per GPU).
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP events on the launch
-stream, inside the timed region) and, at N=1, `cpu_baseline` (the torch-CPU restatement of the
-reference path timed on this host's cores).
+stream) and, at N=1, `cpu_baseline` (the torch-CPU restatement of the reference path timed on
+this host's cores).  lcrec_encode_assign runs two chunk pipelines by default, so launches in the
+timed region overlap each other; the kernel's own rate is then measured in a short untimed pass
+with one pipeline, and the in-region per-launch figures are reported next to it
+(`roofline.in_region`).  `--pipelines 1` times and measures the same, un-overlapped launches.
 """
 import argparse
 import json
@@ -142,6 +145,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--items", type=int, default=0, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelines", type=int, default=0,
+                    help="chunk pipelines of lcrec_encode_assign (LCREC_ENC_STREAMS); 0 = the library's default (2)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo = rehearsal of the N>1 code path, "
                          "ranks may then share one GPU")
@@ -172,6 +177,9 @@ def main():
     import lcrec_amd
     from lcrec_amd import ops
     lcrec_amd._lib.load()
+    if args.pipelines:
+        os.environ["LCREC_ENC_STREAMS"] = str(args.pipelines)
+    pipelines = max(1, min(2, int(os.environ.get("LCREC_ENC_STREAMS", "2"))))
 
     wl = WORKLOADS[args.workload]
     n = args.items or wl["items"]
@@ -200,6 +208,24 @@ def main():
     elapsed = time.perf_counter() - t0
     trace = ops.trace_collect()
     ops.trace_enable(False)
+    # With more than one chunk pipeline two layers' kernels share the chip, so the hipEvent brackets of the timed region
+    # measure launches that overlap each other.  The roofline of the kernel itself is therefore taken in a second,
+    # untimed pass with ONE pipeline (same inputs, same launches, nothing overlapped); the in-region figures are kept
+    # next to it.  `python bench.py --pipelines 1` makes the two coincide (that is the command profiled for profiles/).
+    solo_trace, solo_steps = None, 0
+    if pipelines > 1:
+        solo_steps = min(args.steps, 3)
+        os.environ["LCREC_ENC_STREAMS"] = "1"
+        step()
+        barrier()
+        ops.trace_enable(True)
+        for _ in range(solo_steps):
+            idx_solo = step()
+        barrier()
+        solo_trace = ops.trace_collect()
+        ops.trace_enable(False)
+        os.environ["LCREC_ENC_STREAMS"] = str(pipelines)
+        assert torch.equal(idx_solo, idx)                      # pipelines change scheduling, never results
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -231,9 +257,16 @@ def main():
             # read the activations and the weights once, write the outputs once
             alg_bytes[kname] = alg_bytes.get(kname, 0.0) + 4.0 * (rows * dims[l] + out * dims[l] + rows * out) * args.steps
     dom = max(flops, key=lambda k: flops[k])
-    launches, total_ms = trace.get(dom, (0, 0.0))
-    flops_dom_total = flops[dom]
-    achieved = flops_dom_total / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
+
+    def kernel_rate(tr, steps):
+        launches, total_ms = tr.get(dom, (0, 0.0))
+        fl = flops[dom] * steps / args.steps
+        ach = fl / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
+        return launches, total_ms, fl, ach
+
+    in_launches, in_ms, in_flops, in_ach = kernel_rate(trace, args.steps)
+    launches, total_ms, flops_dom_total, achieved = kernel_rate(solo_trace, solo_steps) if solo_trace else \
+        (in_launches, in_ms, in_flops, in_ach)
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
     if os.path.exists(pmc_file):
@@ -244,7 +277,12 @@ def main():
         "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
         "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
         "flops_per_launch": (flops_dom_total / launches) if launches else None,
-        "algorithmic_bytes_per_launch": (alg_bytes[dom] / launches) if launches else None,
+        "algorithmic_bytes_per_launch": (alg_bytes[dom] / in_launches) if in_launches else None,
+        "measured": ("hipEvent pairs around every launch of the kernel, in the timed region" if not solo_trace else
+                     f"hipEvent pairs around every launch of the kernel in an untimed pass of {solo_steps} steps with one chunk "
+                     f"pipeline; the timed region runs {pipelines} pipelines whose launches overlap (see in_region)"),
+        "in_region": {"pipelines": pipelines, "launches": in_launches,
+                      "avg_launch_ms": (in_ms / in_launches) if in_launches else None, "achieved_per_launch": in_ach},
         "kernel_ms": {k: round(v[1], 3) for k, v in trace.items()},
     }
 
@@ -258,6 +296,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "items_per_gpu": n, "in_dim": wl["in_dim"], "mlp": HIDDEN,
                        "e_dim": E_DIM, "levels": len(ks), "codes_per_level": ks[0], "sharding": f"items/{world}",
+                       "chunk_pipelines": pipelines,
                        "flop_per_item": 2 * macs_all, "bytes_per_item": 4 * wl["in_dim"] + 8 * len(ks)},
             "roofline": roofline,
             "e2e_mfma_frac": value / world * 2 * macs_all / 1e12 / PEAK_F32_MFMA_TFLOPS,

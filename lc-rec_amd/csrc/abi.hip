@@ -53,6 +53,7 @@ void trace_end(hipStream_t stream)
 // Items per pass of the encoder chain: bounds the activation scratch
 // (2 x chunk x widest hidden layer) while keeping every GEMM launch >> 256 tiles.
 constexpr int64_t ENC_CHUNK = 131072;
+constexpr int ENC_PIPES_MAX = 2;      // measured: a third and fourth pipeline add nothing (and cost 2 GB of scratch each)
 
 struct EncLayout {
     int64_t chunk;
@@ -118,7 +119,7 @@ LCREC_API size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n
 {
     if (!dims || n_layers < 1 || n_layers > LCREC_MAX_LAYERS || !K || L < 1) return 0;
     EncLayout o = enc_layout(n, dims, n_layers, K, L);
-    return 2 * o.act_bytes + o.latent_bytes + o.rq_bytes;
+    return 2 * ENC_PIPES_MAX * o.act_bytes + o.latent_bytes + o.rq_bytes;      // an activation ping-pong pair per chunk pipeline
 }
 
 LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers,
@@ -140,23 +141,55 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
         return fail(LCREC_EWORKSPACE, "encode_assign: workspace %zu B < required %zu B", workspace_bytes, need);
     const EncLayout o = enc_layout(n, dims, n_layers, K, L);
     char *ws = reinterpret_cast<char *>(workspace);
-    float *act[2] = {reinterpret_cast<float *>(ws), reinterpret_cast<float *>(ws + o.act_bytes)};
-    float *latent = latent_out ? latent_out : reinterpret_cast<float *>(ws + 2 * o.act_bytes);
-    void *rq_ws = ws + 2 * o.act_bytes + o.latent_bytes;
+    float *latent = latent_out ? latent_out : reinterpret_cast<float *>(ws + 2 * ENC_PIPES_MAX * o.act_bytes);
+    void *rq_ws = ws + 2 * ENC_PIPES_MAX * o.act_bytes + o.latent_bytes;
     const int e = dims[n_layers];
     hipStream_t s = (hipStream_t)stream;
 
-    for (int64_t i0 = 0; i0 < n; i0 += o.chunk) {
+    // Chunk pipelines: chunk c runs on pipeline c % P, pipeline 0 being the caller's stream and the others helper
+    // streams forked from it and joined back before the quantiser pass -- so P layers' kernels are in flight at once
+    // and their workgroups interleave on the CUs: one kernel's store bursts, prologues, narrow tail layers and last
+    // partial round run under another's K loops.  Measured on C3: P = 2 is +1.7 % over P = 1, P = 3 and 4 give nothing.
+    // LCREC_ENC_STREAMS sets P (default 2; 1 = everything on the caller's stream).  The call still does not synchronise
+    // with the host.
+    const char *pipes_env = getenv("LCREC_ENC_STREAMS");           // read per call: bench.py times both settings in one process
+    int pipes_cfg = pipes_env ? atoi(pipes_env) : 2;
+    pipes_cfg = pipes_cfg < 1 ? 1 : (pipes_cfg > ENC_PIPES_MAX ? ENC_PIPES_MAX : pipes_cfg);
+    static thread_local hipStream_t helper[ENC_PIPES_MAX] = {nullptr};
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join[ENC_PIPES_MAX] = {nullptr};
+    const int64_t n_chunks = (n + o.chunk - 1) / o.chunk;
+    const int P = (int)(n_chunks < pipes_cfg ? n_chunks : pipes_cfg);
+    for (int p = 1; p < P; ++p) {
+        if (helper[p]) continue;
+        if ((!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) ||
+            hipStreamCreateWithFlags(&helper[p], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join[p], hipEventDisableTiming) != hipSuccess)
+            return fail(LCREC_EHIP, "encode_assign: cannot create a helper stream");
+    }
+    if (P > 1) {
+        (void)hipEventRecord(ev_fork, s);
+        for (int p = 1; p < P; ++p) (void)hipStreamWaitEvent(helper[p], ev_fork, 0);
+    }
+    int64_t c = 0;
+    for (int64_t i0 = 0; i0 < n; i0 += o.chunk, ++c) {
         const int64_t m = (n - i0 < o.chunk) ? n - i0 : o.chunk;
         const float *src = x + i0 * dims[0];
+        const int pipe = (int)(c % P);
+        hipStream_t cs = pipe ? helper[pipe] : s;
+        float *act[2] = {reinterpret_cast<float *>(ws + (size_t)(2 * pipe) * o.act_bytes),
+                         reinterpret_cast<float *>(ws + (size_t)(2 * pipe + 1) * o.act_bytes)};
         for (int l = 0; l < n_layers; ++l) {
             const bool last = l == n_layers - 1;
             float *dst = last ? latent + i0 * e : act[l & 1];
             int rc = linear_forward(src, m, dims[l], W[l], b[l], bn_scale ? bn_scale[l] : nullptr,
-                                    bn_shift ? bn_shift[l] : nullptr, last ? 0 : 1, dims[l + 1], dst, s);
+                                    bn_shift ? bn_shift[l] : nullptr, last ? 0 : 1, dims[l + 1], dst, cs);
             if (rc) return rc;
             src = dst;
         }
+    }
+    for (int p = 1; p < P; ++p) {
+        (void)hipEventRecord(ev_join[p], helper[p]);
+        (void)hipStreamWaitEvent(s, ev_join[p], 0);
     }
     return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, 0, sse_out, nullptr, rq_ws, o.rq_bytes, s);
 }
