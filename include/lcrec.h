@@ -118,7 +118,11 @@ int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, co
  *              may be NULL, or hold NULL entries for layers without BatchNorm);
  *              ReLU follows every layer but the last (layers.py:27-30)
  *   latent_out device [n][e] or NULL  encoder output
- *   others     as lcrec_rq_assign */
+ *   others     as lcrec_rq_assign
+ * Items are processed in chunks of 131072 on two chunk pipelines: `stream` and a library-owned helper
+ * stream that is forked from `stream` by an event at entry and joined back into it before the quantiser
+ * pass, so everything is ordered after prior work on `stream` and before later work on it, without any
+ * host synchronisation (LCREC_ENC_STREAMS=1 keeps all launches on `stream`). */
 size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n_layers, const int *K, int L);
 int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers,
                         const float *const *W, const float *const *b,
