@@ -155,8 +155,14 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
     const char *pipes_env = getenv("LCREC_ENC_STREAMS");           // read per call: bench.py times both settings in one process
     int pipes_cfg = pipes_env ? atoi(pipes_env) : 2;
     pipes_cfg = pipes_cfg < 1 ? 1 : (pipes_cfg > ENC_PIPES_MAX ? ENC_PIPES_MAX : pipes_cfg);
-    static thread_local hipStream_t helper[ENC_PIPES_MAX] = {nullptr};
-    static thread_local hipEvent_t ev_fork = nullptr, ev_join[ENC_PIPES_MAX] = {nullptr};
+    // helper streams and events belong to a device: one set per (thread, device), created on first use
+    struct Pipes { hipStream_t helper[ENC_PIPES_MAX]; hipEvent_t fork, join[ENC_PIPES_MAX]; };
+    static thread_local Pipes per_device[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(LCREC_EHIP, "encode_assign: hipGetDevice failed");
+    hipStream_t *helper = per_device[dev].helper;
+    hipEvent_t &ev_fork = per_device[dev].fork;
+    hipEvent_t *ev_join = per_device[dev].join;
     const int64_t n_chunks = (n + o.chunk - 1) / o.chunk;
     const int P = (int)(n_chunks < pipes_cfg ? n_chunks : pipes_cfg);
     for (int p = 1; p < P; ++p) {
