@@ -954,13 +954,36 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
         hipError_t he = hipMemcpyAsync(triples_dev, triples.data(), sizeof(int64_t) * triples.size(), hipMemcpyHostToDevice, stream);
         if (he == hipSuccess) he = hipStreamSynchronize(stream);   // triples is a host temporary
         if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn_assign: %s", hipGetErrorString(he));
+        // The size classes are independent (disjoint rows of idx_out).  The slab launch is a hundred or so long-running
+        // workgroups; it goes to a helper stream forked from `stream` (and joined back below), so the tens of thousands of
+        // short workgroups of the LDS classes fill the CUs it leaves idle.
+        struct Side { hipStream_t s; hipEvent_t fork, join; };
+        static thread_local Side side[16] = {};
+        int dev = 0;
+        const bool fork_slab = count[SK_SLAB] > 0 && (count[0] + count[1] + count[2] + count[3]) > 0 &&
+                               hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
+        if (fork_slab && !side[dev].s) {
+            if (hipStreamCreateWithFlags(&side[dev].s, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&side[dev].fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&side[dev].join, hipEventDisableTiming) != hipSuccess)
+                return fail(LCREC_EHIP, "sinkhorn_assign: cannot create the helper stream");
+        }
+        if (fork_slab) {
+            (void)hipEventRecord(side[dev].fork, stream);
+            (void)hipStreamWaitEvent(side[dev].s, side[dev].fork, 0);
+        }
         const int64_t *t = triples_dev;
         for (int cls = 0; cls < NCLS; ++cls) {
             if (!count[cls]) continue;
-            int rc = cls == SK_SLAB ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab, stream)
+            int rc = cls == SK_SLAB ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab,
+                                                              fork_slab ? side[dev].s : stream)
                                     : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, stream);
             if (rc) return rc;
             t += (size_t)3 * count[cls];
+        }
+        if (fork_slab) {
+            (void)hipEventRecord(side[dev].join, side[dev].s);
+            (void)hipStreamWaitEvent(stream, side[dev].join, 0);
         }
     }
     // larger problems (a training batch) go through the multi-launch path, one at a time
