@@ -46,7 +46,7 @@ def main():
         torch.cuda.synchronize()
         return out, time.perf_counter() - t0
 
-    gen.assign_all(model, x[:4096])
+    gen.assign_all(model, x[:300_000])          # warm-up: every kernel form and the helper stream have been used once
     (idx, resid_last, ks), t_pass1 = timed(lambda: gen.assign_all(model, x))
     first = ops.collision_groups(idx, ks, want_groups=False)
     ops.trace_enable(True)
