@@ -972,18 +972,12 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
             (void)hipEventRecord(side[dev].fork, stream);
             (void)hipStreamWaitEvent(side[dev].s, side[dev].fork, 0);
         }
-        // the slab launch goes out FIRST: once the short workgroups saturate the CUs, a 1024-thread workgroup does not
-        // find half a CU free until their grid has almost drained
-        if (count[SK_SLAB]) {
-            const int64_t *ts = triples_dev + (size_t)3 * (count[0] + count[1] + count[2] + count[3]);
-            int rc = launch_sk_small_e<true>(e, r, cb, K, ts, count[SK_SLAB], maxg[SK_SLAB], eps, iters, idx_out, idx_stride, qslab,
-                                             fork_slab ? side[dev].s : stream);
-            if (rc) return rc;
-        }
         const int64_t *t = triples_dev;
-        for (int cls = 0; cls < SK_SLAB; ++cls) {
+        for (int cls = 0; cls < NCLS; ++cls) {
             if (!count[cls]) continue;
-            int rc = launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, stream);
+            int rc = cls == SK_SLAB ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab,
+                                                              fork_slab ? side[dev].s : stream)
+                                    : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, stream);
             if (rc) return rc;
             t += (size_t)3 * count[cls];
         }
