@@ -227,7 +227,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const int n0 = bn * BN;
     // (Measured and dropped: static per-workgroup s_setprio levels cost 4 %, start-up staggering of
     // co-resident workgroups changed nothing, double-buffered LDS with one barrier per K-tile lost 5-10 % at
-    // Games-sized launches -- the second buffer costs a co-resident workgroup.)
+    // Games-sized launches -- the second buffer costs a co-resident workgroup.  At batch-sized launches (1-4 k rows,
+    // about one workgroup per CU) neither prefetch distance 2 with two register sets nor that plus a second LDS buffer
+    // and one barrier per K-tile moved the time by more than 3 % either way, and 128 x 64 / 64 x 128 tiles were slower
+    // on all but the widest layer: those launches are 15-90 us and bound by their few K-chains per SIMD.)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1201,7 +1204,6 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
         return fail(LCREC_EUNSUPPORTED, "linear_forward: in_dim=%d is not a multiple of 8", in_dim);
     if (((uintptr_t)x | (uintptr_t)W) & 15)
         return fail(LCREC_EINVAL, "linear_forward: x and W must be 16-byte aligned");
-    if (n == 0) return LCREC_OK;
     // Wide layers: the ping-pong kernel (one 512-thread workgroup per CU) wins as soon as its 256 x 128 tiles fill
     // the 256 CUs in whole rounds: at least one round, and either >= 8 rounds or <= 20 % of the last round empty
     // (measured with tools/pp_sweep.sh: 8 192 x 768->2048 = 512 tiles: 117 vs 89 TFLOP/s; 16 896 x 1024->512 = 264
