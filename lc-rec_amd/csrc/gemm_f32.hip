@@ -203,8 +203,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Ws[BN * LDK];
+    // one allocation: the epilogue stages 4 x 32 output rows from its start, which is more than As when BM = 64
+    static_assert(BM + BN >= 128, "the epilogue needs 128 staging rows");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float *const As = smem, *const Ws = smem + BM * LDK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;

@@ -392,18 +392,40 @@ __global__ __launch_bounds__(THREADS) void sk_small_kernel(const float *__restri
             if (lane == 0) rsum[t] = s;
         }
         __syncthreads();
+        // Eight rows at a time: the loads of a batch are issued together.  Written one row at a time, every load waits
+        // for the store before it (the compiler cannot prove Q[t*K+j] and Q[(t+1)*K+j] distinct), and with Q in the
+        // slab that made an iteration a chain of 2g L2 round trips (117 us at g = 256).  Same operations, same order.
         for (int j = tid; j < K; j += THREADS) {                 // Q /= rowsum; Q /= B; column sums (:100-103)
+            double *col = Q + j;
             double s = 0.0;
-            for (int t = 0; t < g; ++t) {
-                double v = Q[(size_t)t * K + j] / rsum[t];
+            int t = 0;
+            for (; t + 8 <= g; t += 8) {
+                double v[8], rs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u] = col[(size_t)(t + u) * K]; rs[u] = rsum[t + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = divB(v[u] / rs[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { col[(size_t)(t + u) * K] = v[u]; s += v[u]; }
+            }
+            for (; t < g; ++t) {
+                double v = col[(size_t)t * K] / rsum[t];
                 v = divB(v);
-                Q[(size_t)t * K + j] = v;
+                col[(size_t)t * K] = v;
                 s += v;
             }
             csum[j] = s;
-            for (int t = 0; t < g; ++t) {                            // Q /= colsum; Q /= K (:103-104)
-                double v = Q[(size_t)t * K + j] / s;
-                Q[(size_t)t * K + j] = divK(v);
+            t = 0;
+            for (; t + 8 <= g; t += 8) {                             // Q /= colsum; Q /= K (:103-104)
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(t + u) * K];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) col[(size_t)(t + u) * K] = divK(v[u] / s);
+            }
+            for (; t < g; ++t) {
+                double v = col[(size_t)t * K] / s;
+                col[(size_t)t * K] = divK(v);
             }
         }
         __syncthreads();
@@ -580,11 +602,12 @@ static inline int sk_class(int64_t sz, int K)
     return sz <= SKS_SLAB_MAX_ROWS ? SK_SLAB : SK_BATCH;
 }
 
-// slab_ok: whether the mid-sized groups (class 2) of this call run side by side, one workgroup each, or one after
-// another as batch-sized problems.  One workgroup walks its g x K matrix ~5 times per iteration out of L2: about
-// 1.5 us per row at K = 256 for 50 iterations (1024 threads); a batch-sized solve costs ~0.7 ms whatever its size.
-// A training step's single 2048-row group must take the batch path (0.7 ms, not 3); a collision round's hundred
-// groups of 65..3000 rows must not (4 ms side by side, not 80 ms in a row).
+// slab_ok: whether the mid-sized groups (class SK_SLAB) of this call run side by side, one workgroup each, or one
+// after another as batch-sized problems.  One workgroup needs about 12 us per row at K = 256 for 50 iterations
+// (measured alone: 64 rows 0.9 ms, 256 rows 3.0 ms, 400 rows 4.9 ms -- K of its 1024 threads do the divisions of a
+// column); a batch-sized solve spreads the rows over 64-128 CUs and costs 0.4-0.55 ms whatever its size.  So a
+// training step's single group of 256 or 2048 rows must take the batch path, and a collision round's hundred groups
+// of 65..3000 rows must not (a few ms side by side, not 50+ ms in a row).
 struct SkPlan { int64_t slab_doubles; int64_t biggest; int n_slab; bool slab_ok; };
 
 static SkPlan sk_plan(int K, const int64_t *offs, int G)
@@ -600,8 +623,8 @@ static SkPlan sk_plan(int K, const int64_t *offs, int G)
         if (cls >= SK_SLAB && sz > mid_biggest) mid_biggest = sz;
         if (cls == SK_BATCH && sz > p.biggest) p.biggest = sz;
     }
-    const double side_by_side_us = (double)mid_max * 1.5 * (K / 256.0) * ((n_mid + 255) / 256);
-    p.slab_ok = n_mid > 0 && side_by_side_us <= 700.0 * n_mid;
+    const double side_by_side_us = (double)mid_max * 12.0 * (K / 256.0) * ((n_mid + 255) / 256);
+    p.slab_ok = n_mid > 0 && side_by_side_us <= 500.0 * n_mid;
     if (p.slab_ok) {
         p.n_slab = n_mid;
     } else {
@@ -626,21 +649,78 @@ size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G)
 // workgroups -- through global memory behind a grid barrier, once per iteration.  Same divisions in
 // the same order as the multi-launch path, so the same bits.
 //
-// Grid barrier (guide: Guideline 16, counter form): monotonic agent-scope counter zeroed by a memset
+// Exchange of the column sums, once per iteration, WITHOUT a barrier: the values are their own flags.  Every slot
+// of the exchange buffers starts as a sentinel (all-ones, a NaN no arithmetic produces); writers use agent-scope relaxed
+// atomic stores, readers agent-scope atomic loads, re-reading a slot until it is not the sentinel.  Two hand-overs:
+//   A  workgroup X stores its K partials to part[it % 3][X][.];
+//   B  the OWNER of column j (workgroup j % nblk) reads part[it % 3][0..nblk)[j], adds them in workgroup order (the
+//      same order, hence the same bits, as before) and stores fin[it % 3][j];
+//   C  every workgroup reads the K finished sums fin[it % 3][.].
+// That is two store -> load trips through memory and ~4 KB of traffic per workgroup, against store, release fence,
+// counter add, poll, acquire fence and 128 KB of loads per workgroup for the counter barrier this replaces (in-kernel
+// stamps, tools/sk_stamp_probe.py: 31.7 k cycles per iteration, 9.9 k of them arithmetic).
+// Re-arming: at the START of iteration `it` a workgroup resets its own slots of part[(it + 1) % 3] and fin[(it + 1) % 3]
+// and waits for those stores (vmcnt) before it stores anything of `it`.  Those buffers last carried iteration it - 2,
+// and whoever is in iteration `it` has read every sum of it - 1, each built from every workgroup's partials of it - 1,
+// which each of them stored after it had finished reading it - 2: nobody reads those slots any more.  And whoever
+// polls them for it + 1 has read sums of `it` that were built from this workgroup's partials of `it`, stored after
+// the reset had reached memory: nobody sees a stale value.  (With two buffers the first argument fails.)
+//
+// The grand total before the first iteration still uses a grid barrier (guide: Guideline 16, counter form), which also
+// publishes the sentinels: monotonic agent-scope counter zeroed by a memset
 // node before the launch; lane 0 of each workgroup release-fences, adds 1, polls relaxed with
 // s_sleep until all workgroups of this phase have arrived, acquire-fences, then the workgroup's
 // barrier releases the other waves.  Every workgroup must be resident: the launcher only takes this
-// path for <= SKP_MAX_BLOCKS workgroups (one per CU, half the chip) and the spin is bounded -- on
+// path for <= SKP_MAX_BLOCKS workgroups (one per CU, half the chip) and every spin is bounded -- on
 // timeout the kernel sets *flag and finishes (result invalid, reported by the host), it never hangs.
 // ------------------------------------------------------------------------------------------
+#ifdef LCREC_GEMM_STAMP
+// diagnostic builds (make STAMP=1): cycles workgroup 0 spends in each part of an iteration, summed over iterations >= 1
+__device__ unsigned long long g_sk_stamps[8];
+#define SK_STAMP(slot)                                                                             \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                                 \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            g_sk_stamps[slot] += t_ - sk_t_;                                                       \
+            sk_t_ = t_;                                                                            \
+        }                                                                                          \
+    } while (0)
+#define SK_STAMP_DECL unsigned long long sk_t_ = 0; if (blockIdx.x == 0 && threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sk_t_)::"memory")
+#else
+#define SK_STAMP(slot) do { } while (0)
+#define SK_STAMP_DECL do { } while (0)
+#endif
 constexpr int SKP_THREADS = 512;
 constexpr int SKP_WAVES = SKP_THREADS / 64;
 constexpr int SKP_MAX_BLOCKS = 128;
 constexpr unsigned SKP_SPIN_LIMIT = 40u * 1000u * 1000u;     // ~ seconds of polling with s_sleep
+constexpr unsigned long long SKP_EMPTY = ~0ull;               // exchange slot not written yet
+
+__device__ __forceinline__ void skp_put(double *slot, unsigned long long bits)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long skp_peek(const double *slot)
+{
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the slot's value once it has one (bounded spin; on timeout *flag is set and whatever is there is returned)
+__device__ __forceinline__ double skp_take(const double *slot, unsigned long long first, unsigned *flag)
+{
+    unsigned long long v = first;
+    unsigned spins = 0;
+    while (v == SKP_EMPTY) {
+        __builtin_amdgcn_s_sleep(1);
+        v = skp_peek(slot);
+        if (++spins > SKP_SPIN_LIMIT) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    return __builtin_bit_cast(double, v);
+}
 
 struct SkPersist {
     const float *d;        // [B][K] fp32 distances
-    double *col_part;      // [2][nblk][K]
+    double *col_part;      // [3][nblk][K] partials, then [3][K] finished sums
     double *tot_part;      // [nblk]
     const unsigned *minmax;
     unsigned *counter;     // grid-barrier arrivals (zeroed before launch)
@@ -652,20 +732,30 @@ struct SkPersist {
     int64_t idx_stride;
 };
 
+#ifdef LCREC_GEMM_STAMP
+#define SKP_BARRIER(c, t, f) skp_grid_barrier(c, t, f, sk_t_)
+__device__ __forceinline__ void skp_grid_barrier(unsigned *counter, unsigned target, unsigned *flag, unsigned long long &sk_t_)
+#else
+#define SKP_BARRIER(c, t, f) skp_grid_barrier(c, t, f)
 __device__ __forceinline__ void skp_grid_barrier(unsigned *counter, unsigned target, unsigned *flag)
+#endif
 {
     __syncthreads();
+    SK_STAMP(2);
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SK_STAMP(3);
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SKP_SPIN_LIMIT) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
+        SK_STAMP(4);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SK_STAMP(5);
     }
     __syncthreads();
 }
@@ -676,7 +766,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
     constexpr int ROWS = RW * SKP_WAVES;             // rows per workgroup
     extern __shared__ __attribute__((aligned(16))) double skp_sm[];
     double *colsum = skp_sm;                          // [K]
-    double *colacc = skp_sm + p.K;                    // [SKP_WAVES][K]
+    double *colacc = skp_sm + p.K;                    // [SKP_WAVES][K] (+ nblk: also the owner's gather buffer)
     __shared__ double wsum[SKP_WAVES];
     __shared__ double total_sh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -713,7 +803,14 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
         for (int w = 0; w < SKP_WAVES; ++w) s += wsum[w];
         p.tot_part[blockIdx.x] = s;
     }
-    skp_grid_barrier(p.counter, (++phase) * (unsigned)p.nblk, p.flag);
+    double *const fin_base = p.col_part + (size_t)3 * p.nblk * K;                              // [3][K]
+    const int owned = (int)blockIdx.x < K ? (K - (int)blockIdx.x + p.nblk - 1) / p.nblk : 0;   // columns X, X + nblk, ...
+    for (int j = threadIdx.x; j < 3 * K; j += SKP_THREADS)       // this workgroup's slot in each of the three buffers
+        skp_put(p.col_part + ((size_t)(j / K) * p.nblk + blockIdx.x) * K + j % K, SKP_EMPTY);
+    for (int c = threadIdx.x; c < 3 * owned; c += SKP_THREADS)   // and the sums it owns
+        skp_put(fin_base + (size_t)(c / owned) * K + blockIdx.x + (c % owned) * p.nblk, SKP_EMPTY);
+    SK_STAMP_DECL;
+    SKP_BARRIER(p.counter, (++phase) * (unsigned)p.nblk, p.flag);
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int b = 0; b < p.nblk; ++b) s += p.tot_part[b];
@@ -723,6 +820,13 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
     const double total = total_sh;
 
     for (int it = 0; it < p.iters; ++it) {
+        SK_STAMP(7);
+        if (it > 0) {                                            // re-arm the buffer of the NEXT iteration (see above)
+            double *arm = p.col_part + ((size_t)((it + 1) % 3) * p.nblk + blockIdx.x) * K;
+            for (int j = threadIdx.x; j < K; j += SKP_THREADS) skp_put(arm + j, SKP_EMPTY);
+            double *arm_fin = fin_base + (size_t)((it + 1) % 3) * K + blockIdx.x;
+            for (int c = threadIdx.x; c < owned; c += SKP_THREADS) skp_put(arm_fin + c * p.nblk, SKP_EMPTY);
+        }
         double acc[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] = 0.0;
@@ -758,37 +862,44 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
             if (j < K) colacc[wave * K + j] = acc[c];
         }
         __syncthreads();
-        double *out = p.col_part + ((size_t)(it & 1) * p.nblk + blockIdx.x) * K;
+        SK_STAMP(0);
+        double *out = p.col_part + ((size_t)(it % 3) * p.nblk + blockIdx.x) * K;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the re-arming stores have reached memory
         for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
             double s = 0.0;
             for (int w = 0; w < SKP_WAVES; ++w) s += colacc[w * K + j];
-            out[j] = s;
+            skp_put(out + j, __builtin_bit_cast(unsigned long long, s));
         }
-        skp_grid_barrier(p.counter, (++phase) * (unsigned)p.nblk, p.flag);
-        // colsum[j] = sum over workgroups, in workgroup order (every workgroup computes the same bits).
-        // The loads are issued 16 at a time: a one-at-a-time loop is a chain of L2 round trips.
-        const double *cp = p.col_part + (size_t)(it & 1) * p.nblk * K;
-        for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
+        __syncthreads();                                         // colacc has been read: it is the gather buffer now
+        SK_STAMP(1);
+        // B: the sums this workgroup owns, partials added in workgroup order
+        const double *pb = p.col_part + (size_t)(it % 3) * p.nblk * K + blockIdx.x;
+        for (int i = threadIdx.x; i < owned * p.nblk; i += SKP_THREADS) {
+            const double *slot = pb + (size_t)(i % p.nblk) * K + (i / p.nblk) * p.nblk;
+            colacc[i] = skp_take(slot, skp_peek(slot), p.flag);
+        }
+        __syncthreads();
+        SK_STAMP(2);
+        double *fin = fin_base + (size_t)(it % 3) * K;
+        for (int c = threadIdx.x; c < owned; c += SKP_THREADS) {
+            const double *g = colacc + c * p.nblk;
             double s = 0.0;
             int b = 0;
-            for (; b + 64 <= p.nblk; b += 64) {     // 64 loads in flight (one L2 round trip), then the adds in workgroup order
-                double v[64];
-#pragma unroll
-                for (int t = 0; t < 64; ++t) v[t] = __builtin_nontemporal_load(cp + (size_t)(b + t) * K + j);
-#pragma unroll
-                for (int t = 0; t < 64; ++t) s += v[t];
-            }
-            for (; b + 16 <= p.nblk; b += 16) {
+            for (; b + 16 <= p.nblk; b += 16) {                  // 16 LDS reads in flight, then the adds in workgroup order
                 double v[16];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) v[t] = __builtin_nontemporal_load(cp + (size_t)(b + t) * K + j);
+                for (int t = 0; t < 16; ++t) v[t] = g[b + t];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) s += v[t];
             }
-            for (; b < p.nblk; ++b) s += cp[(size_t)b * K + j];
-            colsum[j] = s;
+            for (; b < p.nblk; ++b) s += g[b];
+            skp_put(fin + blockIdx.x + c * p.nblk, __builtin_bit_cast(unsigned long long, s));
         }
+        SK_STAMP(3);
+        // C: all K sums
+        for (int j = threadIdx.x; j < K; j += SKP_THREADS) colsum[j] = skp_take(fin + j, skp_peek(fin + j), p.flag);
         __syncthreads();
+        SK_STAMP(6);
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -821,7 +932,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
 template <int CPL, int RW>
 static void launch_skp(const SkPersist &p, hipStream_t stream)
 {
-    const size_t lds = (size_t)(1 + SKP_WAVES) * p.K * sizeof(double);
+    const size_t lds = ((size_t)(1 + SKP_WAVES) * p.K + p.nblk) * sizeof(double);
     hipLaunchKernelGGL((sk_persistent_kernel<CPL, RW>), dim3((unsigned)p.nblk), dim3(SKP_THREADS), lds, stream, p);
 }
 
@@ -852,19 +963,24 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
 
     // one-launch register-resident path when every workgroup can be resident (see sk_persistent_kernel)
     const int cpl = (K + 63) / 64;
-    const int rows_p = cpl <= 4 ? 32 : (cpl <= 8 ? 16 : 8);
+    // K = 256 (the reference's codebook size): two rows per wave instead of four when that still fits 128 workgroups
+    // (B <= 2048) -- twice the CUs on the divisions, 22.2 k -> 18.9 k cycles per iteration.  LCREC_SK_RW=4 disables.
+    static const int rw_env = [] { const char *e = getenv("LCREC_SK_RW"); return e ? atoi(e) : 2; }();
+    const bool rw2 = rw_env == 2 && cpl == 4 && (B + 15) / 16 <= SKP_MAX_BLOCKS;
+    const int rows_p = rw2 ? 16 : cpl <= 4 ? 32 : (cpl <= 8 ? 16 : 8);
     const int64_t nblk_p = (B + rows_p - 1) / rows_p;
     static const bool allow_persistent = [] { const char *e = getenv("LCREC_SINKHORN_PERSISTENT"); return !e || atoi(e) != 0; }();
-    if (allow_persistent && nblk_p <= SKP_MAX_BLOCKS && nblk_p <= nblk * 4) {
+    if (allow_persistent && nblk_p <= SKP_MAX_BLOCKS && nblk_p <= nblk * 4 && (3 * (int64_t)K + 1) * nblk_p + 3 * (int64_t)K <= B * (int64_t)K) {
         SkPersist q;
         // the Q region ([B][K] doubles) is unused on this path and holds the exchange buffers:
-        // 2*nblk_p*K + nblk_p doubles <= B*K/4 + B/8
-        q.d = d; q.col_part = p.Q; q.tot_part = p.Q + (size_t)2 * nblk_p * K; q.minmax = minmax;
+        // 3*nblk_p*K partials + 3*K sums + nblk_p totals (checked above)
+        q.d = d; q.col_part = p.Q; q.tot_part = p.Q + (size_t)3 * nblk_p * K + (size_t)3 * K; q.minmax = minmax;
         q.counter = minmax + 4; q.flag = minmax + 5;
         q.B = B; q.K = K; q.nblk = (int)nblk_p; q.iters = iters; q.eps = eps;
         q.idx_out = idx_out; q.idx_stride = idx_stride;
         if (cpl <= 1) launch_skp<1, 4>(q, stream);
         else if (cpl <= 2) launch_skp<2, 4>(q, stream);
+        else if (rw2) launch_skp<4, 2>(q, stream);
         else if (cpl <= 4) launch_skp<4, 4>(q, stream);
         else if (cpl <= 8) launch_skp<8, 2>(q, stream);
         else launch_skp<16, 1>(q, stream);
@@ -1161,3 +1277,15 @@ int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *c
 }
 
 }  // namespace lcrec
+
+#ifdef LCREC_GEMM_STAMP
+extern "C" __attribute__((visibility("default"))) int lcrec_debug_sk_stamps(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(lcrec::g_sk_stamps), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(lcrec::g_sk_stamps), z, sizeof z);
+    }
+    return (int)e;
+}
+#endif

@@ -166,7 +166,7 @@ def _ref_sinkhorn_idx(z, cb, eps, iters):
     return torch.argmax(Q, -1).numpy(), margin
 
 
-@pytest.mark.parametrize("B,K,e", [(2048, 256, 32), (1000, 256, 32), (300, 100, 16), (4096, 1024, 32), (130, 256, 64)])
+@pytest.mark.parametrize("B,K,e", [(2048, 256, 32), (1000, 256, 32), (256, 256, 32), (300, 100, 16), (4096, 1024, 32), (130, 256, 64)])
 def test_sinkhorn_training_batch(hip, B, K, e):
     rs = _rs(B + K)
     z = rs.standard_normal((B, e)).astype(np.float32)
@@ -181,9 +181,9 @@ def test_sinkhorn_training_batch(hip, B, K, e):
     # fp64 exp/sum order differs from torch CPU by ulps: only rows whose top-2 margin is at that level may move
     assert not (bad & (margin > 1e-9)).any(), f"{bad.sum()} rows differ, min margin of those {margin[bad].min()}"
     assert bad.mean() < 1e-3
-    if B >= 1000:
-        # a lone batch-sized problem must take the multi-workgroup solver, not the one-workgroup-per-group
-        # kernel of the collision rounds (that is 10 ms instead of 0.8 ms per training step)
+    if B * K > 16384:
+        # a lone problem beyond the LDS classes (any --batch_size from 65 rows up) must take the multi-workgroup
+        # solver, not the one-workgroup-per-group kernels of the collision rounds (3 ms at 256 rows instead of 0.4)
         assert "sinkhorn" in trace and not ({"sinkhorn_small", "sinkhorn_slab", "sinkhorn_tiny"} & set(trace)), trace
 
 
@@ -211,7 +211,8 @@ def test_sinkhorn_collision_groups(hip, K, e):
     cap = max(2, min(40, 16384 // K))
     sizes = list(rs.randint(2, cap + 1, size=60)) + [1, 2, cap]
     # groups too large for LDS keep Q in the workspace slab, still one workgroup each and side by side
-    sizes += {256: [65, 300, 700], 16: [1500, 1025], 1024: [17, 130]}[K]
+    # (enough of them that side by side beats one batch-sized solve after another: see sk_plan)
+    sizes += {256: [65, 300, 700] + [100] * 20, 16: [1500, 1025] + [1100] * 4, 1024: [17, 130] + [20] * 12}[K]
     if K == 16:
         sizes.append(5000)       # beyond the slab limit: a batch-sized problem, multi-launch path
     offs = np.concatenate([[0], np.cumsum(sizes)])
@@ -223,8 +224,12 @@ def test_sinkhorn_collision_groups(hip, K, e):
     cb = (0.8 * rs.standard_normal((K, e))).astype(np.float32)
     dev = torch.device("cuda:0")
     idx = torch.full((n, 3), -1, dtype=torch.int64, device=dev)
+    hip.ops.trace_enable(True)
     hip.ops.sinkhorn_assign(torch.from_numpy(z).to(dev), torch.from_numpy(cb).to(dev), 0.003, 50,
                             group_offsets=offs.tolist(), out=idx[:, 2])
+    trace = hip.ops.trace_collect()
+    hip.ops.trace_enable(False)
+    assert "sinkhorn_slab" in trace and ("sinkhorn_small" in trace or "sinkhorn_tiny" in trace), trace
     got = idx[:, 2].cpu().numpy()
     assert (idx[:, :2] == -1).all()
     nbad = 0

@@ -26,7 +26,9 @@ def trainer_probe(a):
     n = a.batch * 16
     with tempfile.TemporaryDirectory() as tmp:
         argv = ["--data_path", "unused", "--ckpt_dir", tmp, "--device", dev, "--batch_size", str(a.batch), "--epochs", "4",
-                "--no_kmeans_init"] + ([] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else [])
+                "--no_kmeans_init", "--num_emb_list", "256", "256", "256", "256",          # run.sh: 4 levels, Sinkhorn on the last
+                "--sk_epsilons", "0.0", "0.0", "0.0", "0.0" if a.no_sk else "0.003"] \
+            + ([] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else [])
         args = cli.parse_args(argv)
         cli.seed_everything(2024)
         model = cli.build_model(args, a.in_dim)
@@ -42,7 +44,7 @@ def trainer_probe(a):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         steps = epochs * len(loader)
-        print(f"Trainer._train_epoch: in_dim {a.in_dim} batch {a.batch} bn {a.bn} strict_nan_check {a.strict}: {dt / steps * 1e3:.3f} ms/step, "
+        print(f"Trainer._train_epoch: in_dim {a.in_dim} batch {a.batch} levels 4 sinkhorn {not a.no_sk} bn {a.bn} strict_nan_check {a.strict}: {dt / steps * 1e3:.3f} ms/step, "
               f"{a.batch * steps / dt:,.0f} items/s")
 
 
