@@ -15,8 +15,38 @@ _c_int_p = ctypes.POINTER(ctypes.c_int)
 _workspaces = {}
 
 
+# Host cost matters: a training step makes ~50 calls into the library, and torch.cuda.current_stream() /
+# torch.cuda.device() cost 5-10 us each (Stream objects, index normalisation) -- as much as the launch itself.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream_int(index=None):
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device() if index is None else index)
+    return torch.cuda.current_stream(index).cuda_stream
+
+
 def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_int())
+
+
+class _on:
+    """`with _on(device)`: torch.cuda.device(device), skipped when that device is already current."""
+    __slots__ = ("guard",)
+
+    def __init__(self, device):
+        same = _cur_device is not None and device.index is not None and device.index == _cur_device()
+        self.guard = None if same else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            return self.guard.__exit__(*exc)
+        return False
 
 
 def _dev(t, name):
@@ -37,7 +67,7 @@ def _ints(values):
 
 def _workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream); reuse is safe because calls are stream-ordered."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_int(device.index))
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -62,7 +92,7 @@ def linear_forward(x, weight, bias=None, bn_scale=None, bn_shift=None, relu=Fals
     if weight.shape[1] != k:
         raise _lib.LcrecError(f"weight is {tuple(weight.shape)}, x is {tuple(x.shape)}")
     y = torch.empty((n, out_dim), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.lcrec_linear_forward(_ptr(x), n, k, _ptr(weight), _ptr(bias), _ptr(bn_scale), _ptr(bn_shift),
                                       int(bool(relu)), out_dim, _ptr(y), _stream_ptr())
     _lib.check(rc, "lcrec_linear_forward")
@@ -81,7 +111,7 @@ def linear_backward(gy, x, weight, need_gx=True, need_gw=True):
         raise _lib.LcrecError(f"linear_backward: shapes gy {tuple(gy.shape)}, x {tuple(x.shape)}, W {tuple(weight.shape)}")
     gx = torch.empty((n, in_dim), dtype=torch.float32, device=gy.device) if need_gx else None
     gw = torch.empty((out_dim, in_dim), dtype=torch.float32, device=gy.device) if need_gw else None
-    with torch.cuda.device(gy.device):
+    with _on(gy.device):
         nbytes = lib.lcrec_linear_backward_workspace(n, in_dim, out_dim) if need_gw else 0
         ws = _workspace(nbytes, gy.device)
         rc = lib.lcrec_linear_backward(_ptr(gy), _ptr(x), _ptr(weight), n, in_dim, out_dim, _ptr(gx), _ptr(gw), _ptr(ws),
@@ -124,7 +154,7 @@ def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=F
     sse = torch.zeros(L, dtype=torch.float64, device=dev) if want_sse else None
     resid = torch.empty((L + 1, n, e), dtype=torch.float32, device=dev) if want_resid else None
     karr = _ints(ks)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = lib.lcrec_rq_assign_workspace(n, e, karr, L)
         ws = _workspace(nbytes, dev)
         rc = lib.lcrec_rq_assign(_ptr(z), n, e, _ptr(cb), karr, L, _ptr(idx), _ptr(xq), int(xq_init is not None),
@@ -165,7 +195,7 @@ def encode_assign(x, weights, biases, codebooks_flat, ks, bn_scales=None, bn_shi
     scp = PA(*[0 if t is None else t.data_ptr() for t in scs])
     shp = PA(*[0 if t is None else t.data_ptr() for t in shs])
     darr, karr = _ints(dims), _ints(ks)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = lib.lcrec_encode_assign_workspace(n, darr, nl, karr, L)
         ws = _workspace(nbytes, dev)
         rc = lib.lcrec_encode_assign(_ptr(x), n, darr, nl, wp, bp, scp, shp, _ptr(cb), karr, L, _ptr(idx),
@@ -198,7 +228,7 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
         out = torch.zeros(n, dtype=torch.int64, device=resid.device)
     out, stride = _idx_col(out, n)
     oarr = offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
-    with torch.cuda.device(resid.device):
+    with _on(resid.device):
         nbytes = lib.lcrec_sinkhorn_assign_workspace(n, K, oarr, G)
         ws = _workspace(nbytes, resid.device)
         rc = lib.lcrec_sinkhorn_assign(_ptr(resid), n, e, _ptr(codebook), K, oarr, G, float(epsilon), int(iters),
@@ -275,7 +305,7 @@ def rq_apply_level(resid, codebook, idx, xq=None, want_sse=False):
         raise _lib.LcrecError("xq must be a contiguous [n, e] float32 device tensor")
     nxt = torch.empty_like(resid)
     sse = torch.zeros(1, dtype=torch.float64, device=resid.device) if want_sse else None
-    with torch.cuda.device(resid.device):
+    with _on(resid.device):
         ws = _workspace(8192, resid.device)
         rc = lib.lcrec_rq_apply_level(_ptr(resid), n, e, _ptr(codebook), K, _ptr(idx), stride, _ptr(xq),
                                       int(accumulate), _ptr(nxt), _ptr(sse), _ptr(ws), ws.numel(), _stream_ptr())
@@ -291,7 +321,7 @@ def code_stats(idx, resid, K):
     idx, stride = _idx_col(idx, n)
     count = torch.empty(K, dtype=torch.float32, device=resid.device)
     total = torch.empty((K, e), dtype=torch.float32, device=resid.device)
-    with torch.cuda.device(resid.device):
+    with _on(resid.device):
         rc = lib.lcrec_code_stats(_ptr(idx), stride, _ptr(resid), n, e, K, _ptr(count), _ptr(total), _stream_ptr())
     _lib.check(rc, "lcrec_code_stats")
     return count, total
@@ -307,7 +337,7 @@ def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps):
     K, e = codebook.shape
     alpha = 1 - decay                  # the reference's python doubles, rounded to fp32 at the ABI
     keep = 1 - (1 - decay)
-    with torch.cuda.device(codebook.device):
+    with _on(codebook.device):
         rc = lib.lcrec_ema_update(_ptr(ema_count), _ptr(ema_sum), _ptr(codebook), _ptr(count), _ptr(total), K, e,
                                   decay, alpha, keep, eps, _stream_ptr())
     _lib.check(rc, "lcrec_ema_update")
@@ -331,7 +361,7 @@ def collision_groups(idx, ks, want_groups=True):
     members = torch.empty(max(n, 1), dtype=torch.int64, device=dev) if want_groups else None
     offsets = torch.empty(n // 2 + 2, dtype=torch.int64, device=dev) if want_groups else None
     karr = _ints(ks)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = lib.lcrec_collision_groups_workspace(n, L)
         ws = _workspace(nbytes, dev)
         rc = lib.lcrec_collision_groups(_ptr(idx), n, L, karr, _ptr(members), _ptr(offsets), _ptr(counters), _ptr(ws),

@@ -177,6 +177,7 @@ class Trainer(object):
         total_recon = torch.zeros((), dtype=torch.float64, device=self.device)
         iter_data = tqdm(train_data, total=len(train_data), ncols=100, desc=set_color(f"Train {epoch_idx}", "pink"),
                          disable=not self._is_main())
+        params = list(self.model.parameters())          # one walk of the module tree per epoch, not per step
         # no host synchronisation inside a step: the launch queue stays a step ahead of the GPU
         with ops.deferred_checks() as checks:
             for data in iter_data:
@@ -191,7 +192,7 @@ class Trainer(object):
                 loss.backward()
                 if self.dist is not None:
                     self.dist.reduce_gradients(self.model, n_local=data.shape[0])
-                torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+                torch.nn.utils.clip_grad_norm_(params, 1.0)
                 self.optimizer.step()
                 self.scheduler.step()
                 # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step;

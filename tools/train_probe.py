@@ -37,12 +37,21 @@ def trainer_probe(a):
         trainer = Trainer(args, model, len(loader))
         trainer._train_epoch(loader, 0)
         torch.cuda.synchronize()
+        prof = None
+        if a.cprofile:                                   # host side of the timed epochs only (main thread)
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         epochs = max(1, a.steps // len(loader))
         for e in range(epochs):
             trainer._train_epoch(loader, e + 1)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof).sort_stats("tottime").print_stats(30)
         steps = epochs * len(loader)
         print(f"Trainer._train_epoch: in_dim {a.in_dim} batch {a.batch} levels 4 sinkhorn {not a.no_sk} bn {a.bn} strict_nan_check {a.strict}: {dt / steps * 1e3:.3f} ms/step, "
               f"{a.batch * steps / dt:,.0f} items/s")
@@ -57,6 +66,7 @@ def main():
     ap.add_argument("--ema", action="store_true")
     ap.add_argument("--no_sk", action="store_true")
     ap.add_argument("--strict", action="store_true", help="with --trainer: the per-step NaN host sync of the reference")
+    ap.add_argument("--cprofile", action="store_true", help="with --trainer: cProfile of the timed epochs")
     ap.add_argument("--trainer", action="store_true",
                     help="time lcrec_amd.trainer.Trainer._train_epoch itself (loader, NaN check, fused AdamW, schedule)")
     a = ap.parse_args()
