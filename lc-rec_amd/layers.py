@@ -52,6 +52,49 @@ class _LinearAct(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _MlpChain(torch.autograd.Function):
+    """A run of [Linear, ReLU?] groups as ONE autograd node: the same library calls in the same order as a chain of
+    _LinearAct nodes (bit-identical values and gradients), without a Python `apply` and an autograd-engine hop per
+    layer -- at batch sizes up to ~1 k a training step is bound by exactly that host work."""
+
+    @staticmethod
+    def forward(ctx, x, relus, *params):
+        saved = []
+        h = x
+        for l, relu in enumerate(relus):
+            w, b = params[2 * l], params[2 * l + 1]
+            y = ops.linear_forward(h, w, b, relu=relu)
+            saved += [h, w, y if relu else None]
+            h = y
+        ctx.relus = relus
+        ctx.save_for_backward(*saved)
+        return h
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        L = len(ctx.relus)
+        grads = [None] * (2 * L)
+        g = gy.contiguous()
+        for l in range(L - 1, -1, -1):
+            x, weight, y = saved[3 * l], saved[3 * l + 1], saved[3 * l + 2]
+            if ctx.relus[l]:
+                g = torch.ops.aten.threshold_backward(g, y, 0.0)
+            if ctx.needs_input_grad[2 + 2 * l + 1]:
+                grads[2 * l + 1] = g.sum(0)
+            out_dim = weight.shape[0]
+            pad = (-out_dim) % 32                      # see _LinearAct.backward
+            if pad:
+                g = F.pad(g, (0, pad))
+                weight = F.pad(weight, (0, 0, 0, pad))
+            need_gx = l > 0 or ctx.needs_input_grad[0]
+            gx, gw = ops.linear_backward(g, x, weight, need_gx, ctx.needs_input_grad[2 + 2 * l])
+            if gw is not None:
+                grads[2 * l] = gw[:out_dim] if pad else gw
+            g = gx
+        return (g if ctx.needs_input_grad[0] else None, None, *grads)
+
+
 def fold_batchnorm(bn):
     """Eval-mode BatchNorm1d as an affine y = t*scale + shift (fp32, on the module's device)."""
     scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
@@ -129,10 +172,27 @@ class MLPLayers(nn.Module):
         """True when every activation is ReLU (the only one the GEMM epilogue implements)."""
         return all(("act" not in g) or isinstance(self.mlp_layers[g["act"]], nn.ReLU) for g in self._groups)
 
+    def _chainable(self):
+        """Differentiating through plain [Linear, ReLU?] groups (no BatchNorm, no active dropout, bias present):
+        the whole stack is one autograd node."""
+        if not torch.is_grad_enabled() or (self.training and self.dropout > 0):
+            return False
+        mods = self.mlp_layers
+        return all("bn" not in g and mods[g["linear"]].bias is not None
+                   and ("act" not in g or isinstance(mods[g["act"]], nn.ReLU)) for g in self._groups)
+
     def forward(self, input_feature):
         x = input_feature
         if x.dim() != 2:
             x = x.reshape(-1, x.shape[-1])
+        if self._chainable():
+            mods = self.mlp_layers
+            relus = tuple("act" in g for g in self._groups)
+            params = []
+            for g in self._groups:
+                params += [mods[g["linear"]].weight, mods[g["linear"]].bias]
+            x = _MlpChain.apply(x, relus, *params)
+            return x.reshape(*input_feature.shape[:-1], x.shape[-1])
         for g in self._groups:
             mods = self.mlp_layers
             if self.training and self.dropout > 0:
