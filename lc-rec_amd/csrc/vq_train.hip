@@ -933,6 +933,9 @@ template <int CPL, int RW>
 static void launch_skp(const SkPersist &p, hipStream_t stream)
 {
     const size_t lds = ((size_t)(1 + SKP_WAVES) * p.K + p.nblk) * sizeof(double);
+    if (lds > 48 * 1024)        // K = 1024: 75 KB (a failure here surfaces through check_launch at the caller)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_persistent_kernel<CPL, RW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((sk_persistent_kernel<CPL, RW>), dim3((unsigned)p.nblk), dim3(SKP_THREADS), lds, stream, p);
 }
 

@@ -166,7 +166,8 @@ def _ref_sinkhorn_idx(z, cb, eps, iters):
     return torch.argmax(Q, -1).numpy(), margin
 
 
-@pytest.mark.parametrize("B,K,e", [(2048, 256, 32), (1000, 256, 32), (256, 256, 32), (300, 100, 16), (4096, 1024, 32), (130, 256, 64)])
+@pytest.mark.parametrize("B,K,e", [(2048, 256, 32), (1000, 256, 32), (256, 256, 32), (300, 100, 16), (4096, 1024, 32), (1000, 1024, 32),
+                                   (130, 256, 64)])
 def test_sinkhorn_training_batch(hip, B, K, e):
     rs = _rs(B + K)
     z = rs.standard_normal((B, e)).astype(np.float32)
