@@ -395,6 +395,9 @@ __global__ __launch_bounds__(THREADS) void sk_small_kernel(const float *__restri
         // Eight rows at a time: the loads of a batch are issued together.  Written one row at a time, every load waits
         // for the store before it (the compiler cannot prove Q[t*K+j] and Q[(t+1)*K+j] distinct), and with Q in the
         // slab that made an iteration a chain of 2g L2 round trips (117 us at g = 256).  Same operations, same order.
+        // (Measured and dropped for the slab kernel: four threads per column instead of one, and row sums four rows at
+        // a time -- its launches did not get shorter: they last as long as their largest group, whose ~2 g K divisions
+        // per iteration run on one CU, ~12 us per row.)
         for (int j = tid; j < K; j += THREADS) {                 // Q /= rowsum; Q /= B; column sums (:100-103)
             double *col = Q + j;
             double s = 0.0;
@@ -1076,33 +1079,43 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
         // The size classes are independent (disjoint rows of idx_out).  The slab launch is a hundred or so long-running
         // workgroups; it goes to a helper stream forked from `stream` (and joined back below), so the tens of thousands of
         // short workgroups of the LDS classes fill the CUs it leaves idle.
-        struct Side { hipStream_t s; hipEvent_t fork, join; };
+        // Likewise the three larger LDS classes (thousands of mid-length workgroups, launches with long tails) go to a
+        // second helper stream beside the pair/triple class on the caller's: 20 rounds at 1 M items 148 -> 130-140 ms.
+        // LCREC_SK_SIDE2=0 keeps them on the caller's stream.
+        struct Side { hipStream_t s[2]; hipEvent_t fork, join[2]; };
         static thread_local Side side[16] = {};
+        static const int side2 = [] { const char *e = getenv("LCREC_SK_SIDE2"); return e ? atoi(e) : 1; }();
         int dev = 0;
-        const bool fork_slab = count[SK_SLAB] > 0 && (count[0] + count[1] + count[2] + count[3]) > 0 &&
-                               hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
-        if (fork_slab && !side[dev].s) {
-            if (hipStreamCreateWithFlags(&side[dev].s, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&side[dev].fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&side[dev].join, hipEventDisableTiming) != hipSuccess)
-                return fail(LCREC_EHIP, "sinkhorn_assign: cannot create the helper stream");
+        const int n_lds = count[0] + count[1] + count[2] + count[3];
+        const bool can_fork = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
+        const bool fork_slab = can_fork && count[SK_SLAB] > 0 && n_lds > 0;
+        const bool fork_mid = can_fork && side2 && count[0] > 0 && (count[1] + count[2] + count[3]) > 0;
+        if ((fork_slab || fork_mid) && !side[dev].s[0]) {
+            bool ok = hipEventCreateWithFlags(&side[dev].fork, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 2 && ok; ++i)
+                ok = hipStreamCreateWithFlags(&side[dev].s[i], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&side[dev].join[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) return fail(LCREC_EHIP, "sinkhorn_assign: cannot create the helper streams");
         }
-        if (fork_slab) {
-            (void)hipEventRecord(side[dev].fork, stream);
-            (void)hipStreamWaitEvent(side[dev].s, side[dev].fork, 0);
-        }
+        if (fork_slab || fork_mid) (void)hipEventRecord(side[dev].fork, stream);
+        if (fork_slab) (void)hipStreamWaitEvent(side[dev].s[0], side[dev].fork, 0);
+        if (fork_mid) (void)hipStreamWaitEvent(side[dev].s[1], side[dev].fork, 0);
         const int64_t *t = triples_dev;
         for (int cls = 0; cls < NCLS; ++cls) {
             if (!count[cls]) continue;
-            int rc = cls == SK_SLAB ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab,
-                                                              fork_slab ? side[dev].s : stream)
-                                    : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, stream);
+            hipStream_t on = cls == SK_SLAB ? (fork_slab ? side[dev].s[0] : stream) : (cls > 0 && fork_mid ? side[dev].s[1] : stream);
+            int rc = cls == SK_SLAB ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab, on)
+                                    : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, on);
             if (rc) return rc;
             t += (size_t)3 * count[cls];
         }
         if (fork_slab) {
-            (void)hipEventRecord(side[dev].join, side[dev].s);
-            (void)hipStreamWaitEvent(stream, side[dev].join, 0);
+            (void)hipEventRecord(side[dev].join[0], side[dev].s[0]);
+            (void)hipStreamWaitEvent(stream, side[dev].join[0], 0);
+        }
+        if (fork_mid) {
+            (void)hipEventRecord(side[dev].join[1], side[dev].s[1]);
+            (void)hipStreamWaitEvent(stream, side[dev].join[1], 0);
         }
     }
     // larger problems (a training batch) go through the multi-launch path, one at a time
