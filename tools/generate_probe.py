@@ -49,6 +49,12 @@ def main():
     w_idx, w_resid, w_ks = gen.assign_all(model, x[:300_000])   # warm-up: every kernel form and both helper streams used once
     gen.resolve_collisions(model, w_idx, w_resid, w_ks)
     (idx, resid_last, ks), t_pass1 = timed(lambda: gen.assign_all(model, x))
+    if os.environ.get("PROBE_TRACE_PASS1"):
+        ops.trace_enable(True)
+        _, t_again = timed(lambda: gen.assign_all(model, x))
+        tr = ops.trace_collect()
+        ops.trace_enable(False)
+        print(f"pass 1 again, traced: {t_again * 1e3:.1f} ms; " + ", ".join(f"{k} {v[1]:.1f} ms/{v[0]}" for k, v in sorted(tr.items(), key=lambda kv: -kv[1][1])))
     first = ops.collision_groups(idx, ks, want_groups=False)
     ops.trace_enable(True)
     (idx, history), t_rounds = timed(lambda: gen.resolve_collisions(model, idx, resid_last, ks))
