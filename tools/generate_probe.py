@@ -49,6 +49,12 @@ def main():
     w_idx, w_resid, w_ks = gen.assign_all(model, x[:300_000])   # warm-up: every kernel form and both helper streams used once
     gen.resolve_collisions(model, w_idx, w_resid, w_ks)
     (idx, resid_last, ks), t_pass1 = timed(lambda: gen.assign_all(model, x))
+    if os.environ.get("PROBE_REPEAT"):                     # is a slow pass 1 sticky, and does it need two chunk pipelines?
+        for streams in ("2", "1", "2"):
+            os.environ["LCREC_ENC_STREAMS"] = streams
+            _, t_rep = timed(lambda: gen.assign_all(model, x))
+            print(f"pass 1 repeated, LCREC_ENC_STREAMS={streams}: {t_rep * 1e3:.1f} ms")
+        del os.environ["LCREC_ENC_STREAMS"]
     if os.environ.get("PROBE_TRACE_PASS1"):
         ops.trace_enable(True)
         _, t_again = timed(lambda: gen.assign_all(model, x))
