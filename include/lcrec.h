@@ -144,7 +144,13 @@ int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers
  *   codebook       device [K][e]
  *   group_offsets  HOST  [n_groups+1] ascending row offsets; group g = rows [off[g], off[g+1])
  *   idx_out        device int64, element i written at idx_out[i*idx_stride]
- * e must be 16, 32 or 64; K <= 1024 for groups too large for LDS (rows*K > 16384). */
+ * e must be 16, 32 or 64; K <= 1024 for groups too large for LDS (rows*K > 16384).
+ * With several groups the call buckets them by size and launches the buckets on `stream` and on up to two
+ * library-owned helper streams, forked from `stream` by an event and joined back into it before the call
+ * returns its last launch: ordered after prior and before later work on `stream`.  It waits once on the host
+ * for the upload of the group table (many-group calls only; a single training batch never synchronises).
+ * A lone group of more than 16384/K rows is solved by one multi-workgroup launch whose workgroups must all be
+ * resident (<= 128 workgroups); if its bounded spin ever times out, idx_out is filled with -1. */
 size_t lcrec_sinkhorn_assign_workspace(int64_t n, int K, const int64_t *group_offsets, int n_groups);
 int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *codebook, int K,
                           const int64_t *group_offsets, int n_groups, double epsilon, int iters,
