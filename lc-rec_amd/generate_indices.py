@@ -60,19 +60,50 @@ def get_collision_item(all_indices_str):
     return [ids for ids in seen.values() if len(ids) > 1]
 
 
-def load_checkpoint(ckpt_path):
-    """torch.load of a trainer checkpoint ({args, epoch, best_*, state_dict, optimizer},
-    trainer.py:158-166) allowing only argparse.Namespace beyond plain tensors."""
-    import pickle
-    try:
-        with torch.serialization.safe_globals([argparse.Namespace]):
-            return torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=True)
-    except pickle.UnpicklingError:
-        # trainer.py:167 writes pickle protocol 4, whose FRAME opcode torch's restricted unpickler does
-        # not implement; a trainer checkpoint is the user's own file, so load it the way the reference
-        # does (generate_indices.py:51 predates the weights_only default).
-        log.info("restricted unpickler cannot read %s (protocol 4); loading with weights_only=False", ckpt_path)
+# Globals a trainer checkpoint ({args, epoch, best_*, state_dict, optimizer}, trainer.py:158-166) needs beyond
+# plain containers and numbers: tensor rebuild helpers, typed storages, OrderedDict, and argparse.Namespace for `args`.
+_CKPT_GLOBALS = {("collections", "OrderedDict"), ("argparse", "Namespace"),
+                 ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+                 ("torch", "Size"), ("torch.storage", "UntypedStorage")} | \
+                {("torch", t + "Storage") for t in ("Float", "Double", "Half", "BFloat16", "Long", "Int", "Short",
+                                                    "Char", "Byte", "Bool")}
+
+
+class _CheckpointPickle:
+    """`pickle_module` for torch.load: the real unpickler (so protocol 4's FRAME opcode, which
+    trainer.py:167 makes every checkpoint carry and torch's own weights_only unpickler rejects, is read)
+    with find_class restricted to _CKPT_GLOBALS -- any other global raises instead of being imported."""
+    import pickle as _pickle
+    __name__ = "lcrec_amd.checkpoint_pickle"
+    UnpicklingError = _pickle.UnpicklingError
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            if (module, name) in _CKPT_GLOBALS:
+                return super().find_class(module, name)
+            import pickle
+            raise pickle.UnpicklingError(f"checkpoint names the global {module}.{name}, which is not on the "
+                                         "allow-list of a trainer checkpoint (use --trust_checkpoint for your own files)")
+
+    @classmethod
+    def load(cls, fh, **kw):
+        return cls.Unpickler(fh, **kw).load()
+
+    @classmethod
+    def loads(cls, data, **kw):
+        import io
+        return cls.Unpickler(io.BytesIO(data), **kw).load()
+
+
+def load_checkpoint(ckpt_path, trust=False):
+    """torch.load of a trainer checkpoint with a restricted unpickler: tensors, plain containers and
+    argparse.Namespace (the `args` entry), nothing else -- a file that names any other global is refused
+    with pickle.UnpicklingError, never executed.  `trust=True` (CLI: --trust_checkpoint) loads the way the
+    reference does (generate_indices.py:51, full pickle): only for a file you wrote yourself."""
+    if trust:
+        log.warning("loading %s with the unrestricted unpickler (--trust_checkpoint)", ckpt_path)
         return torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=False)
+    return torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=False, pickle_module=_CheckpointPickle)
 
 
 def build_model_from_args(args, in_dim):
@@ -198,7 +229,7 @@ def sharded_assign(ctx, data, assign_fn, device):
     return ctx.gather_rows(idx), ctx.gather_rows(resid_last), ks
 
 
-def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True, ctx=None):
+def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True, ctx=None, trust_checkpoint=False):
     """Whole flow of generate_indices.py:51-145.  Returns a dict of the statistics it prints.
 
     Under torchrun (ctx = dist.init_from_env()) pass 1 is item-sharded over the ranks; the conflict
@@ -207,7 +238,7 @@ def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=Tr
     ctx = ctx or ldist.current()
     lead = ctx.rank == 0
     verbose = verbose and lead
-    ckpt = load_checkpoint(ckpt_path)
+    ckpt = load_checkpoint(ckpt_path, trust=trust_checkpoint)
     args = ckpt["args"]
     data = EmbDataset(data_path or args.data_path, mmap=ctx.enabled)
     model = build_model_from_args(args, data.dim)
@@ -246,12 +277,15 @@ def main(argv=None):
     ap.add_argument("--output_dir", type=str, required=True)
     ap.add_argument("--data_path", type=str, default=None, help="override the data path stored in the checkpoint")
     ap.add_argument("--device", type=str, default="cuda:0")
+    ap.add_argument("--trust_checkpoint", action="store_true",
+                    help="load the checkpoint with the unrestricted unpickler (executes code from the file)")
     a = ap.parse_args(argv)
     from . import dist as ldist
     ctx = ldist.init_from_env(a)                       # torchrun: one rank per GPU; plain python: inert
     out = os.path.join(a.output_dir, f"{a.dataset}.index.json")
     try:
-        return generate(a.ckpt_path, out, device=a.device, data_path=a.data_path, ctx=ctx)
+        return generate(a.ckpt_path, out, device=a.device, data_path=a.data_path, ctx=ctx,
+                        trust_checkpoint=a.trust_checkpoint)
     finally:
         ldist.shutdown(ctx)
 

@@ -169,6 +169,22 @@ def test_checkpoint_retention_walk_matches_reference(tmp_path):
     assert {k: [list(v.shape), str(v.dtype)] for k, v in ck["state_dict"].items()} == schema["state_dict"]
     assert sorted(ck["optimizer"]) == schema["optimizer_keys"]
     assert ck["epoch"] == schema["epoch"] and ck["best_collision_rate"] == schema["best_collision_rate"]
+    # the index generator reads the same file with the restricted unpickler (no weights_only=False fallback) ...
+    from lcrec_amd import generate_indices as gen
+    safe = gen.load_checkpoint(os.path.join(t.ckpt_dir, "best_collision_model.pth"))
+    assert sorted(safe) == schema["keys"] and vars(safe["args"]) == vars(ck["args"])
+    assert all(torch.equal(v, safe["state_dict"][k]) for k, v in ck["state_dict"].items())
+    # ... and refuses a file that names any other global instead of executing it
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % os.path.join(t.ckpt_dir, "pwned"),))
+    bad = os.path.join(t.ckpt_dir, "crafted.pth")
+    torch.save({"args": Evil(), "state_dict": {}}, bad, pickle_protocol=4)
+    with pytest.raises(pickle.UnpicklingError):
+        gen.load_checkpoint(bad)
+    assert not os.path.exists(os.path.join(t.ckpt_dir, "pwned"))
 
 
 # ------------------------------------------------------------------ data
