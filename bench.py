@@ -108,6 +108,19 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    """Model string of the host CPU (the CPU baseline is quoted with core count AND model)."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=12.0):
     """The reference's CPU path (torch CPU ops of rqvae.py:68-72, restated in oracle/torch_ref.py),
     batch 4096, timed on this host's cores on a bounded sample."""
@@ -132,7 +145,7 @@ def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "items/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": done / dt, "unit": "items/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
             "sample": f"first {done} rows of the same synthetic tensor, batch 4096, fp32, "
                       f"oracle/torch_ref.get_indices (torch CPU ops of rqvae.py:68-72)"}
 
@@ -146,7 +159,7 @@ def main():
     ap.add_argument("--items", type=int, default=0, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelines", type=int, default=0,
-                    help="chunk pipelines of lcrec_encode_assign (LCREC_ENC_STREAMS); 0 = the library's default (2)")
+                    help="chunk pipelines of lcrec_encode_assign (lcrec_context_set_pipelines); 0 = the library's default (2)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo = rehearsal of the N>1 code path, "
                          "ranks may then share one GPU")
@@ -177,9 +190,8 @@ def main():
     import lcrec_amd
     from lcrec_amd import ops
     lcrec_amd._lib.load()
-    if args.pipelines:
-        os.environ["LCREC_ENC_STREAMS"] = str(args.pipelines)
-    pipelines = max(1, min(2, int(os.environ.get("LCREC_ENC_STREAMS", "2"))))
+    pipelines = max(1, min(2, args.pipelines or 2))
+    ops.set_pipelines(pipelines)
 
     wl = WORKLOADS[args.workload]
     n = args.items or wl["items"]
@@ -215,7 +227,7 @@ def main():
     solo_trace, solo_steps = None, 0
     if pipelines > 1:
         solo_steps = min(args.steps, 3)
-        os.environ["LCREC_ENC_STREAMS"] = "1"
+        ops.set_pipelines(1)
         step()
         barrier()
         ops.trace_enable(True)
@@ -224,12 +236,31 @@ def main():
         barrier()
         solo_trace = ops.trace_collect()
         ops.trace_enable(False)
-        os.environ["LCREC_ENC_STREAMS"] = str(pipelines)
+        ops.set_pipelines(pipelines)
         assert torch.equal(idx_solo, idx)                      # pipelines change scheduling, never results
+    # near-tie audit (untimed): rows whose top-2 code gap at some level is within ops.NEARTIE_TAU of the rounding
+    # magnitude -- the only rows a CPU run of the reference could index differently (tests/golden/f9_neartie_*.npz)
+    audit = {}
+    idx_audit = ops.encode_assign(x, Ws, bs, flat, ks, audit=audit, tie_tau=ops.NEARTIE_TAU)[0]
+    assert torch.equal(idx_audit, idx)
+    neartie_rows = int((audit["neartie"] != 0).sum())
+    del audit, idx_audit
+    checksum = int(idx.sum())                        # per-rank: proves every rank computed, and what
+    ranks_seen, checksums = 1, [checksum]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        cdev = device if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # one all-gather of (rank, index checksum, near-tie rows) through the collective backend: `ranks_seen` is the
+        # number of distinct ranks RCCL actually delivered data from
+        mine = torch.tensor([rank, checksum, neartie_rows], dtype=torch.int64, device=cdev)
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        got = torch.stack(got).cpu()
+        ranks_seen = int(got[:, 0].unique().numel())
+        checksums = [int(v) for v in got[:, 1]]
+        neartie_rows = int(got[:, 2].sum())
 
     # Algorithmic flops per GEMM kernel: replay the library's dispatch rule (gemm_f32.hip, linear_forward)
     # over the chunks lcrec_encode_assign walks (131072 rows each).
@@ -275,6 +306,8 @@ def main():
     roofline = {
         "kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+        "traffic_source": "static: profiles/pmc_dominant_kernel.json (separate rocprofv3 --pmc passes, FETCH_SIZE/WRITE_SIZE "
+                          "corrected per the guide), not measured in this run",
         "launches": launches, "avg_launch_ms": (total_ms / launches) if launches else None,
         "flops_per_launch": (flops_dom_total / launches) if launches else None,
         "algorithmic_bytes_per_launch": (alg_bytes[dom] / in_launches) if in_launches else None,
@@ -300,6 +333,11 @@ def main():
                        "flop_per_item": 2 * macs_all, "bytes_per_item": 4 * wl["in_dim"] + 8 * len(ks)},
             "roofline": roofline,
             "e2e_mfma_frac": value / world * 2 * macs_all / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "ranks_seen": ranks_seen, "idx_checksums": checksums,
+            "neartie_rows": neartie_rows, "neartie_tau": ops.NEARTIE_TAU,
+            "neartie_note": "rows (all ranks) whose top-2 code gap at some level is <= tau x distance magnitude: the only rows "
+                            "on which the reference's CPU arithmetic can differ from the canonical order this library and "
+                            "its oracle implement (measured: 33 of 1 M at C3, 0 of 16 859 at C2; DESIGN.md section 2)",
             "io_gbps": value / world * (4 * wl["in_dim"] + 8 * len(ks)) / 1e9,
         }
         if world == 1:
@@ -311,6 +349,7 @@ def main():
                                             threads=host_cores())["idx"]
             out["parity_rows_checked"] = m
             out["parity_mismatch_rows"] = int((idx[:m].cpu().numpy() != want).any(axis=1).sum())
+            out["parity_checker"] = "oracle/lcrec_oracle.c (canonical order); reference-differing rows: see neartie_rows"
             if not args.no_cpu_baseline:
                 sample = x[: min(n, 200_000)].cpu()
                 out["cpu_baseline"] = cpu_baseline(sample, dims, Ws, bs, cbs)

@@ -13,9 +13,18 @@
  *     pointer to a contiguous row-major buffer owned by the caller;
  *     pointers marked "host" are ordinary host arrays (shape descriptors);
  *   - the library allocates nothing that outlives a call: scratch space is a
- *     caller-provided workspace whose size is returned by *_workspace();
- *   - all work is enqueued on `stream` (a hipStream_t, NULL = default stream);
- *     calls never synchronise the device;
+ *     caller-provided workspace whose size is returned by *_workspace().  The one
+ *     exception is explicit: an lcrec_context (create/destroy below) owns the helper
+ *     streams, events and the pinned upload ring that the two calls taking a context
+ *     may use; with a NULL context those calls keep every launch on `stream`;
+ *   - all work is enqueued on `stream` (a hipStream_t, NULL = default stream), or on
+ *     a context's helper streams forked from it and joined back into it before the
+ *     call returns (on every exit path, errors included): a call is ordered after
+ *     prior and before later work on `stream`; calls do not synchronise the device
+ *     (the one documented host wait: lcrec_sinkhorn_assign with many groups and a
+ *     NULL context);
+ *   - no global mutable state apart from the diagnostic trace log; a context is used
+ *     by one host thread at a time (one process per GPU needs no locking);
  *   - return 0 on success, a negative LCREC_E* code otherwise; the message for
  *     the calling thread's last error is lcrec_last_error(); nothing throws;
  *   - arithmetic contract: every contraction is one fp32 fused-multiply-add
@@ -34,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LCREC_ABI_VERSION 1
+#define LCREC_ABI_VERSION 2
 
 #define LCREC_OK 0
 #define LCREC_EINVAL (-1)      /* bad argument (shape, NULL pointer, unsupported size) */
@@ -50,6 +59,24 @@ int lcrec_version(void);
 
 /* Message for the last error returned on the calling thread ("" if none). */
 const char *lcrec_last_error(void);
+
+/* Opaque per-device resources for the calls that can overlap independent launches (SURVEY.md section 8b:
+ * "nothing persistent except an opaque handle with explicit create/destroy").  The reference has no
+ * counterpart: its index/ stage issues every op on one stream (index/main.py:38, one device).
+ * A context belongs to the HIP device that is current when it is created and holds
+ *   - two helper streams with their fork/join events: ONE pool shared by the chunk pipelines of
+ *     lcrec_encode_assign and the size-class launches of lcrec_sinkhorn_assign (so a process never owns
+ *     more than two library streams per device, whatever mix of calls it makes);
+ *   - a ring of pinned host buffers through which lcrec_sinkhorn_assign uploads its group table without
+ *     waiting on the host;
+ *   - settings: the number of chunk pipelines of lcrec_encode_assign (1 or 2; default 2).
+ * Streams, events and pinned buffers are created on first use and released by lcrec_context_destroy,
+ * which first waits for the helper streams to drain. */
+typedef struct lcrec_context lcrec_context;
+int lcrec_context_create(lcrec_context **out);
+int lcrec_context_destroy(lcrec_context *ctx);
+/* chunk pipelines of lcrec_encode_assign: 1 = every launch on the caller's stream, 2 (default) = see there. */
+int lcrec_context_set_pipelines(lcrec_context *ctx, int pipelines);
 
 /* One MLP layer: y = [relu]( [bn]( x @ W^T + b ) ).
  * Replaces one Dropout(p=0)/Linear/[BatchNorm1d eval]/[ReLU] group of
@@ -101,12 +128,25 @@ int lcrec_linear_backward(const float *gy, const float *x, const float *W, int64
  *                                    vq.py:90-92 is (1+beta)*sse/(n*e)
  *   resid_out  device [L+1][n][e] or NULL  entry l = residual fed into level l (input of
  *                                    lcrec_code_stats), entry L = residual after the last level
+ *   margin_out device [n][L] float or NULL  near-tie audit: per item and level, the second smallest
+ *                                    distance minus the smallest, both as computed above (0 on an exact
+ *                                    tie, +inf when K[l] == 1)
+ *   neartie_out device [n] uint32 or NULL   bit l set when margin_l <= tie_tau * (xx_l + cc_l[idx_l]),
+ *                                    the magnitude at which the winning distance of level l was rounded
+ *   tie_tau    threshold for neartie_out (>= 0; ignored when neartie_out is NULL)
  *   workspace  device scratch of lcrec_rq_assign_workspace() bytes
- * e must be 16, 32 or 64. */
+ * e must be 16, 32 or 64.
+ * Why the audit outputs exist: the reference decides vq.py:75 on fp32 distances whose summation order (MKL,
+ * vectorised reductions) is unspecified and batch-size dependent (hard part 1), so an item
+ * whose two best codes are closer than that noise can get a different code from the reference's CPU run than from
+ * this library's canonical order -- and, its residual then differing, different codes on the levels after it.
+ * Items whose neartie_out is 0 at the tau recorded in tests/golden/f9_neartie_*.npz carry the reference's tuple;
+ * DESIGN.md section 2 states the measured rates. */
 size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
                     int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out,
-                    float *resid_out, void *workspace, size_t workspace_bytes, void *stream);
+                    float *resid_out, float *margin_out, uint32_t *neartie_out, float tie_tau,
+                    void *workspace, size_t workspace_bytes, void *stream);
 
 /* Encoder MLP + residual quantisation: item embeddings -> index tuples.
  * Replaces RQVAE.get_indices(xs, use_sk=False), index/models/rqvae.py:68-72
@@ -118,18 +158,21 @@ int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, co
  *              may be NULL, or hold NULL entries for layers without BatchNorm);
  *              ReLU follows every layer but the last (layers.py:27-30)
  *   latent_out device [n][e] or NULL  encoder output
- *   others     as lcrec_rq_assign
- * Items are processed in chunks of 131072 on two chunk pipelines: `stream` and a library-owned helper
- * stream that is forked from `stream` by an event at entry and joined back into it before the quantiser
- * pass, so everything is ordered after prior work on `stream` and before later work on it, without any
- * host synchronisation (LCREC_ENC_STREAMS=1 keeps all launches on `stream`). */
+ *   others     as lcrec_rq_assign (margin_out / neartie_out / tie_tau: the near-tie audit of the quantiser)
+ *   ctx        NULL, or a context of the current device
+ * Items are processed in chunks of 131072.  With a context whose pipelines setting is 2, odd chunks run on
+ * the context's first helper stream, forked from `stream` by an event at entry and joined back into it before
+ * the quantiser pass (and on every error exit), so everything is ordered after prior work on `stream` and
+ * before later work on it, without any host synchronisation; with ctx == NULL or pipelines == 1 every launch
+ * is on `stream`. */
 size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n_layers, const int *K, int L);
 int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers,
                         const float *const *W, const float *const *b,
                         const float *const *bn_scale, const float *const *bn_shift,
                         const float *codebooks, const int *K, int L, int64_t *idx_out,
-                        float *latent_out, float *xq_out, double *sse_out, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        float *latent_out, float *xq_out, double *sse_out,
+                        float *margin_out, uint32_t *neartie_out, float tie_tau,
+                        void *workspace, size_t workspace_bytes, lcrec_context *ctx, void *stream);
 
 /* Sinkhorn ("uniform semantic") assignment of one level, for one or many independent
  * groups of rows.  Replaces the use_sk branch of VectorQuantizer.forward,
@@ -144,18 +187,22 @@ int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers
  *   codebook       device [K][e]
  *   group_offsets  HOST  [n_groups+1] ascending row offsets; group g = rows [off[g], off[g+1])
  *   idx_out        device int64, element i written at idx_out[i*idx_stride]
+ *   ctx            NULL, or a context of the current device
  * e must be 16, 32 or 64; K <= 1024 for groups too large for LDS (rows*K > 16384).
- * With several groups the call buckets them by size and launches the buckets on `stream` and on up to two
- * library-owned helper streams, forked from `stream` by an event and joined back into it before the call
- * returns its last launch: ordered after prior and before later work on `stream`.  It waits once on the host
+ * With several groups the call buckets them by size, one launch per bucket.  With a context the buckets go to
+ * `stream` and to the context's two helper streams, forked from `stream` by an event and joined back into it
+ * before the call returns (error exits included), and the group table reaches the device through the context's
+ * pinned ring: no host wait.  With ctx == NULL every launch is on `stream` and the call waits once on the host
  * for the upload of the group table (many-group calls only; a single training batch never synchronises).
  * A lone group of more than 16384/K rows is solved by one multi-workgroup launch whose workgroups must all be
- * resident (<= 128 workgroups); if its bounded spin ever times out, idx_out is filled with -1. */
+ * resident: it is chosen only when the occupancy the runtime reports for its LDS size times the CU count covers
+ * the grid (<= 128 workgroups), otherwise the multi-launch solver runs; every spin in it is bounded (~0.1 s in
+ * total) and a timeout -- other work holding the CUs -- fills idx_out with -1 instead of hanging. */
 size_t lcrec_sinkhorn_assign_workspace(int64_t n, int K, const int64_t *group_offsets, int n_groups);
 int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *codebook, int K,
                           const int64_t *group_offsets, int n_groups, double epsilon, int iters,
                           int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                          void *stream);
+                          lcrec_context *ctx, void *stream);
 
 /* Apply a given assignment to one level: gather, squared error, straight-through estimator and
  * residual update (index/models/vq.py:87-95, index/models/rq.py:47-48) -- what follows the

@@ -7,6 +7,7 @@ modules can be constructed and (de)serialised anywhere, but every forward needs 
 HIP device and the built library.
 """
 from . import _lib, ops  # noqa: F401
+from .ops import NEARTIE_TAU  # noqa: F401
 from ._lib import LcrecError  # noqa: F401
 from .layers import MLPLayers, kmeans, sinkhorn_algorithm  # noqa: F401
 from .vq import VectorQuantizer  # noqa: F401

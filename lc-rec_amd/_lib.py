@@ -31,19 +31,24 @@ _SIGNATURES = {
                                              ctypes.c_size_t, _vp]),
     "lcrec_rq_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                     ctypes.c_int]),
+    "lcrec_context_create": (ctypes.c_int, [ctypes.POINTER(_vp)]),
+    "lcrec_context_destroy": (ctypes.c_int, [_vp]),
+    "lcrec_context_set_pipelines": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lcrec_rq_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
-                                       ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+                                       ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_float,
+                                       _vp, ctypes.c_size_t, _vp]),
     "lcrec_encode_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                                         ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "lcrec_encode_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                            ctypes.POINTER(_vp), _vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
-                                           _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+                                           _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_size_t, _vp,
+                                           _vp]),
     "lcrec_sinkhorn_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int,
                                                           ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
     "lcrec_sinkhorn_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int,
                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_double,
-                                             ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_size_t, _vp]),
+                                             ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_size_t, _vp, _vp]),
     "lcrec_rq_apply_level": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int, _vp,
                                             ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_code_stats": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
@@ -65,6 +70,7 @@ class TraceEntry(ctypes.Structure):
 
 
 EXPORTS = tuple(_SIGNATURES)
+ABI_VERSION = 2                      # LCREC_ABI_VERSION of include/lcrec.h this binding was written against
 
 _lib = None
 
@@ -86,8 +92,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.lcrec_version() != 1:
-        raise LcrecError(f"ABI version mismatch: library {lib.lcrec_version()}, binding 1")
+    if lib.lcrec_version() != ABI_VERSION:
+        raise LcrecError(f"ABI version mismatch: library {lib.lcrec_version()}, binding {ABI_VERSION} "
+                         "(rebuild: make -C lc-rec_amd/csrc)")
     _lib = lib
     return lib
 

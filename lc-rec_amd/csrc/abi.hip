@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <new>
 #include <vector>
 
 namespace lcrec {
@@ -74,9 +75,103 @@ static EncLayout enc_layout(int64_t n, const int *dims, int n_layers, const int 
     return o;
 }
 
+int check_context(const lcrec_context *ctx, const char *who)
+{
+    if (!ctx) return LCREC_OK;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(LCREC_EHIP, "%s: hipGetDevice failed", who);
+    if (dev != ctx->device) return fail(LCREC_EINVAL, "%s: context belongs to device %d, current device is %d", who, ctx->device, dev);
+    return LCREC_OK;
+}
+
 }  // namespace lcrec
 
 using namespace lcrec;
+
+int lcrec_context::ensure_streams()
+{
+    if (streams_ready) return LCREC_OK;
+    bool ok = fork || hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < HELPERS && ok; ++i) {
+        ok = helper[i] || hipStreamCreateWithFlags(&helper[i], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && (join[i] || hipEventCreateWithFlags(&join[i], hipEventDisableTiming) == hipSuccess);
+    }
+    if (!ok) return fail(LCREC_EHIP, "context: cannot create the helper streams: %s", hipGetErrorString(hipGetLastError()));
+    streams_ready = true;
+    return LCREC_OK;
+}
+
+void *lcrec_context::ring_acquire(size_t bytes, int *slot)
+{
+    const int i = pin_next;
+    pin_next = (pin_next + 1) % RING;
+    if (pin_busy[i]) {                      // RING uploads ago: complete unless the device is that far behind
+        (void)hipEventSynchronize(pin_done[i]);
+        pin_busy[i] = false;
+    }
+    if (pin_bytes[i] < bytes) {
+        if (pin[i]) (void)hipHostFree(pin[i]);
+        pin[i] = nullptr;
+        pin_bytes[i] = 0;
+        const size_t want = align_up(bytes + bytes / 2, 4096);
+        if (hipHostMalloc(&pin[i], want, hipHostMallocDefault) != hipSuccess) {
+            fail(LCREC_EHIP, "context: hipHostMalloc(%zu) failed", want);
+            return nullptr;
+        }
+        pin_bytes[i] = want;
+    }
+    if (!pin_done[i] && hipEventCreateWithFlags(&pin_done[i], hipEventDisableTiming) != hipSuccess) {
+        fail(LCREC_EHIP, "context: cannot create an event");
+        return nullptr;
+    }
+    *slot = i;
+    return pin[i];
+}
+
+void lcrec_context::ring_release(int slot, hipStream_t after)
+{
+    if (hipEventRecord(pin_done[slot], after) == hipSuccess) pin_busy[slot] = true;
+}
+
+LCREC_API int lcrec_context_create(lcrec_context **out)
+{
+    if (!out) return fail(LCREC_EINVAL, "context_create: NULL output");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(LCREC_EHIP, "context_create: no HIP device");
+    lcrec_context *c = new (std::nothrow) lcrec_context();
+    if (!c) return fail(LCREC_EHIP, "context_create: out of host memory");
+    c->device = dev;
+    *out = c;
+    return LCREC_OK;
+}
+
+LCREC_API int lcrec_context_destroy(lcrec_context *c)
+{
+    if (!c) return LCREC_OK;
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess;
+    for (int i = 0; i < lcrec_context::HELPERS; ++i) {
+        if (c->helper[i]) { (void)hipStreamSynchronize(c->helper[i]); (void)hipStreamDestroy(c->helper[i]); }
+        if (c->join[i]) (void)hipEventDestroy(c->join[i]);
+    }
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    for (int i = 0; i < lcrec_context::RING; ++i) {
+        if (c->pin_busy[i]) (void)hipEventSynchronize(c->pin_done[i]);
+        if (c->pin_done[i]) (void)hipEventDestroy(c->pin_done[i]);
+        if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+    }
+    if (switched) (void)hipSetDevice(cur);
+    delete c;
+    return LCREC_OK;
+}
+
+LCREC_API int lcrec_context_set_pipelines(lcrec_context *c, int pipelines)
+{
+    if (!c) return fail(LCREC_EINVAL, "context_set_pipelines: NULL context");
+    if (pipelines < 1 || pipelines > 2) return fail(LCREC_EINVAL, "context_set_pipelines: %d (supported: 1, 2)", pipelines);
+    c->pipelines = pipelines;
+    return LCREC_OK;
+}
 
 LCREC_API int lcrec_version(void) { return LCREC_ABI_VERSION; }
 
@@ -109,10 +204,11 @@ LCREC_API size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L
 
 LCREC_API int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
                               int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out,
-                              float *resid_out, void *workspace, size_t workspace_bytes, void *stream)
+                              float *resid_out, float *margin_out, uint32_t *neartie_out, float tie_tau,
+                              void *workspace, size_t workspace_bytes, void *stream)
 {
-    return rq_assign(z, n, e, codebooks, K, L, idx_out, xq_out, xq_accumulate, sse_out, resid_out, workspace,
-                     workspace_bytes, (hipStream_t)stream);
+    return rq_assign(z, n, e, codebooks, K, L, idx_out, xq_out, xq_accumulate, sse_out, resid_out, margin_out,
+                     neartie_out, tie_tau, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 LCREC_API size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n_layers, const int *K, int L)
@@ -126,8 +222,9 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
                                   const float *const *W, const float *const *b,
                                   const float *const *bn_scale, const float *const *bn_shift,
                                   const float *codebooks, const int *K, int L, int64_t *idx_out,
-                                  float *latent_out, float *xq_out, double *sse_out, void *workspace,
-                                  size_t workspace_bytes, void *stream)
+                                  float *latent_out, float *xq_out, double *sse_out,
+                                  float *margin_out, uint32_t *neartie_out, float tie_tau,
+                                  void *workspace, size_t workspace_bytes, lcrec_context *ctx, void *stream)
 {
     if (n == 0 && dims && K) return LCREC_OK;              // empty batch
     if (!x || !dims || !W || !b || !codebooks || !K || !idx_out)
@@ -139,6 +236,7 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
     const size_t need = lcrec_encode_assign_workspace(n, dims, n_layers, K, L);
     if (!workspace || workspace_bytes < need)
         return fail(LCREC_EWORKSPACE, "encode_assign: workspace %zu B < required %zu B", workspace_bytes, need);
+    if (int rc = check_context(ctx, "encode_assign")) return rc;
     const EncLayout o = enc_layout(n, dims, n_layers, K, L);
     char *ws = reinterpret_cast<char *>(workspace);
     float *latent = latent_out ? latent_out : reinterpret_cast<float *>(ws + 2 * ENC_PIPES_MAX * o.act_bytes);
@@ -146,58 +244,40 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
     const int e = dims[n_layers];
     hipStream_t s = (hipStream_t)stream;
 
-    // Chunk pipelines: chunk c runs on pipeline c % P, pipeline 0 being the caller's stream and the others helper
-    // streams forked from it and joined back before the quantiser pass -- so P layers' kernels are in flight at once
-    // and their workgroups interleave on the CUs: one kernel's store bursts, prologues, narrow tail layers and last
-    // partial round run under another's K loops.  Measured on C3: P = 2 is +1.7 % over P = 1, P = 3 and 4 give nothing.
-    // LCREC_ENC_STREAMS sets P (default 2; 1 = everything on the caller's stream).  The call still does not synchronise
-    // with the host.
-    const char *pipes_env = getenv("LCREC_ENC_STREAMS");           // read per call: bench.py times both settings in one process
-    int pipes_cfg = pipes_env ? atoi(pipes_env) : 2;
-    pipes_cfg = pipes_cfg < 1 ? 1 : (pipes_cfg > ENC_PIPES_MAX ? ENC_PIPES_MAX : pipes_cfg);
-    // helper streams and events belong to a device: one set per (thread, device), created on first use
-    struct Pipes { hipStream_t helper[ENC_PIPES_MAX]; hipEvent_t fork, join[ENC_PIPES_MAX]; };
-    static thread_local Pipes per_device[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(LCREC_EHIP, "encode_assign: hipGetDevice failed");
-    hipStream_t *helper = per_device[dev].helper;
-    hipEvent_t &ev_fork = per_device[dev].fork;
-    hipEvent_t *ev_join = per_device[dev].join;
+    // Chunk pipelines: chunk c runs on pipeline c % P, pipeline 0 being the caller's stream and pipeline 1 the
+    // context's first helper stream, forked from the caller's and joined back before the quantiser pass -- so two
+    // layers' kernels are in flight at once and their workgroups interleave on the CUs: one kernel's store bursts,
+    // prologues, narrow tail layers and last partial round run under the other's K loops.  Measured on C3: P = 2 is
+    // +1.7 % over P = 1, P = 3 and 4 give nothing.  The call still does not synchronise with the host.
     const int64_t n_chunks = (n + o.chunk - 1) / o.chunk;
-    const int P = (int)(n_chunks < pipes_cfg ? n_chunks : pipes_cfg);
-    for (int p = 1; p < P; ++p) {
-        if (helper[p]) continue;
-        if ((!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) ||
-            hipStreamCreateWithFlags(&helper[p], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join[p], hipEventDisableTiming) != hipSuccess)
-            return fail(LCREC_EHIP, "encode_assign: cannot create a helper stream");
-    }
+    int P = ctx ? ctx->pipelines : 1;
+    if (P > ENC_PIPES_MAX) P = ENC_PIPES_MAX;
+    if (n_chunks < P) P = (int)n_chunks;
     if (P > 1) {
-        (void)hipEventRecord(ev_fork, s);
-        for (int p = 1; p < P; ++p) (void)hipStreamWaitEvent(helper[p], ev_fork, 0);
+        if (int rc = ctx->ensure_streams()) return rc;
     }
-    int64_t c = 0;
-    for (int64_t i0 = 0; i0 < n; i0 += o.chunk, ++c) {
-        const int64_t m = (n - i0 < o.chunk) ? n - i0 : o.chunk;
-        const float *src = x + i0 * dims[0];
-        const int pipe = (int)(c % P);
-        hipStream_t cs = pipe ? helper[pipe] : s;
-        float *act[2] = {reinterpret_cast<float *>(ws + (size_t)(2 * pipe) * o.act_bytes),
-                         reinterpret_cast<float *>(ws + (size_t)(2 * pipe + 1) * o.act_bytes)};
-        for (int l = 0; l < n_layers; ++l) {
-            const bool last = l == n_layers - 1;
-            float *dst = last ? latent + i0 * e : act[l & 1];
-            int rc = linear_forward(src, m, dims[l], W[l], b[l], bn_scale ? bn_scale[l] : nullptr,
-                                    bn_shift ? bn_shift[l] : nullptr, last ? 0 : 1, dims[l + 1], dst, cs);
-            if (rc) return rc;
-            src = dst;
+    {
+        ForkJoin fj(ctx, s, P > 1 ? 1u : 0u);              // joins on every exit from this block
+        int64_t c = 0;
+        for (int64_t i0 = 0; i0 < n; i0 += o.chunk, ++c) {
+            const int64_t m = (n - i0 < o.chunk) ? n - i0 : o.chunk;
+            const float *src = x + i0 * dims[0];
+            const int pipe = (int)(c % P);
+            hipStream_t cs = pipe ? fj.on(pipe - 1) : s;
+            float *act[2] = {reinterpret_cast<float *>(ws + (size_t)(2 * pipe) * o.act_bytes),
+                             reinterpret_cast<float *>(ws + (size_t)(2 * pipe + 1) * o.act_bytes)};
+            for (int l = 0; l < n_layers; ++l) {
+                const bool last = l == n_layers - 1;
+                float *dst = last ? latent + i0 * e : act[l & 1];
+                int rc = linear_forward(src, m, dims[l], W[l], b[l], bn_scale ? bn_scale[l] : nullptr,
+                                        bn_shift ? bn_shift[l] : nullptr, last ? 0 : 1, dims[l + 1], dst, cs);
+                if (rc) return rc;
+                src = dst;
+            }
         }
     }
-    for (int p = 1; p < P; ++p) {
-        (void)hipEventRecord(ev_join[p], helper[p]);
-        (void)hipStreamWaitEvent(s, ev_join[p], 0);
-    }
-    return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, 0, sse_out, nullptr, rq_ws, o.rq_bytes, s);
+    return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, 0, sse_out, nullptr, margin_out, neartie_out, tie_tau,
+                     rq_ws, o.rq_bytes, s);
 }
 
 LCREC_API int lcrec_trace_enable(int on)
@@ -241,10 +321,10 @@ LCREC_API size_t lcrec_sinkhorn_assign_workspace(int64_t n, int K, const int64_t
 LCREC_API int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *codebook, int K,
                                     const int64_t *group_offsets, int n_groups, double epsilon, int iters,
                                     int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                                    void *stream)
+                                    lcrec_context *ctx, void *stream)
 {
     return sinkhorn_assign(resid, n, e, codebook, K, group_offsets, n_groups, epsilon, iters, idx_out, idx_stride,
-                           workspace, workspace_bytes, (hipStream_t)stream);
+                           workspace, workspace_bytes, ctx, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_rq_apply_level(const float *resid_in, int64_t n, int e, const float *codebook, int K,

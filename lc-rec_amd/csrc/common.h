@@ -46,6 +46,59 @@ struct TraceScope {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+}  // namespace lcrec
+
+// lcrec_context (include/lcrec.h): the only library-owned resources that outlive a call.
+struct lcrec_context {
+    static constexpr int HELPERS = 2, RING = 4;
+    int device = 0;
+    int pipelines = 2;
+    bool streams_ready = false;
+    hipStream_t helper[HELPERS] = {};
+    hipEvent_t fork = nullptr, join[HELPERS] = {};
+    // pinned upload ring: slot i may be rewritten once pin_done[i] (recorded after the copy that read it) has completed
+    void *pin[RING] = {};
+    size_t pin_bytes[RING] = {};
+    hipEvent_t pin_done[RING] = {};
+    bool pin_busy[RING] = {};
+    int pin_next = 0;
+
+    int ensure_streams();                                   // LCREC_OK or a failed code (last error set)
+    void *ring_acquire(size_t bytes, int *slot);            // pinned host buffer of >= bytes, or NULL (last error set)
+    void ring_release(int slot, hipStream_t after);         // call after enqueueing the copy that reads the slot
+};
+
+namespace lcrec {
+
+// Fork a context's helper streams from `s` (those in `mask`) and join them back on scope exit -- every exit, so an
+// error return never leaves helper work un-ordered against the caller's stream.
+struct ForkJoin {
+    lcrec_context *c;
+    hipStream_t s;
+    unsigned mask;
+    ForkJoin(lcrec_context *ctx, hipStream_t stream, unsigned helpers) : c(ctx), s(stream), mask(ctx ? helpers : 0u)
+    {
+        if (!mask) return;
+        (void)hipEventRecord(c->fork, s);
+        for (int i = 0; i < lcrec_context::HELPERS; ++i)
+            if (mask & (1u << i)) (void)hipStreamWaitEvent(c->helper[i], c->fork, 0);
+    }
+    ~ForkJoin()
+    {
+        for (int i = 0; i < lcrec_context::HELPERS; ++i)
+            if (mask & (1u << i)) {
+                (void)hipEventRecord(c->join[i], c->helper[i]);
+                (void)hipStreamWaitEvent(s, c->join[i], 0);
+            }
+    }
+    hipStream_t on(int i) const { return (mask & (1u << i)) ? c->helper[i] : s; }
+    ForkJoin(const ForkJoin &) = delete;
+    ForkJoin &operator=(const ForkJoin &) = delete;
+};
+
+// LCREC_OK when ctx is NULL or belongs to the current device
+int check_context(const lcrec_context *ctx, const char *who);
+
 // kernels' launchers (host side, enqueue only)
 int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const float *b,
                    const float *bn_scale, const float *bn_shift, int relu, int out_dim, float *y,
@@ -59,12 +112,13 @@ int linear_backward(const float *gy, const float *x, const float *W, int64_t n, 
 size_t rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
               int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
+              float *margin_out, uint32_t *neartie_out, float tie_tau,
               void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G);
 int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
                     int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                    hipStream_t stream);
+                    lcrec_context *ctx, hipStream_t stream);
 int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, const int64_t *idx, int64_t idx_stride,
                 float *xq, int xq_accumulate, float *r_out, double *sse_out, void *workspace, size_t workspace_bytes,
                 hipStream_t stream);

@@ -47,6 +47,9 @@ struct RqParams {
     float *resid_next;     // [n][E] residual after level l1-1, or NULL
     float *resid_levels;   // [L+1][n][E]: entry l = residual entering level l, entry L = final residual; or NULL
     double *sse_partial;   // [gridDim.x][L], or NULL
+    float *margin;         // [n][L]: second smallest distance minus the smallest, per level; or NULL
+    uint32_t *neartie;     // [n]: bit l set when margin_l <= tie_tau * (xx_l + cc_l[idx_l]); or NULL
+    float tie_tau;
 };
 
 __device__ __forceinline__ void swap32(float a, float b, float &lo_pair, float &hi_pair)
@@ -58,7 +61,11 @@ __device__ __forceinline__ void swap32(float a, float b, float &lo_pair, float &
     hi_pair = __uint_as_float(r[1]);
 }
 
-template <int E, int THREADS, bool WANT_XQ>
+// WANT_MARGIN: also track the second smallest distance (the near-tie audit of SURVEY.md section 8b / section 7 hard
+// part 1: rows whose two best codes are closer than the rounding noise of vq.py:71-73 are the only ones on which the
+// reference's own CPU arithmetic can pick a different code).  Same value as the oracle's sequential scan: the minimum
+// over all codes but the winner -- an order-independent quantity, so the per-half partials merge exactly.
+template <int E, int THREADS, bool WANT_XQ, bool WANT_MARGIN>
 __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
 {
     constexpr int S = E + 4;   // padded LDS row (floats)
@@ -143,6 +150,9 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             }
         }
 
+        uint32_t tie_bits = 0;
+        if (WANT_MARGIN && p.neartie && p.l0 > 0 && valid) tie_bits = p.neartie[item];   // levels of earlier launches
+
         for (int l = p.l0; l < p.l1; ++l) {
             const int ro = p.row_off[l];
             const int nblk = (p.K[l] + 31) >> 5;
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             for (int s = 0; s < H; ++s) swap32(r[2 * s], r[2 * s + 1], b0[s], b1[s]);
 
             float best0 = __builtin_inff(), best1 = __builtin_inff();
+            float sec0 = __builtin_inff(), sec1 = __builtin_inff();
             int bi0 = 0, bi1 = 0;
 
             for (int b = 0; b < nblk; ++b) {
@@ -200,11 +211,13 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
                     const float t0 = xx0 + ccv[t];
                     const float d0 = t0 - 2.0f * acc0[t];
                     const bool lt0 = d0 < best0;
+                    if (WANT_MARGIN) sec0 = lt0 ? best0 : (d0 < sec0 ? d0 : sec0);
                     best0 = lt0 ? d0 : best0;
                     bi0 = lt0 ? code : bi0;
                     const float t1 = xx1 + ccv[t];
                     const float d1 = t1 - 2.0f * acc1[t];
                     const bool lt1 = d1 < best1;
+                    if (WANT_MARGIN) sec1 = lt1 ? best1 : (d1 < sec1 ? d1 : sec1);
                     best1 = lt1 ? d1 : best1;
                     bi1 = lt1 ? code : bi1;
                 }
@@ -220,6 +233,17 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             const int bi = takeB ? iB : iA;
 
             if (valid) p.idx_out[item * p.L + l] = (int64_t)bi;
+            if (WANT_MARGIN) {
+                float sA, sB;
+                swap32(sec0, sec1, sA, sB);
+                const float lose = takeB ? dA : dB, wsec = takeB ? sB : sA;     // the loser's best, the winner's second
+                const float win = takeB ? dB : dA;
+                const float second = lose < wsec ? lose : wsec;
+                const float margin = second - win;
+                if (p.margin && valid) p.margin[item * p.L + l] = margin;
+                const float scale = xx + ccs[ro + bi];
+                if (margin <= p.tie_tau * scale) tie_bits |= 1u << l;
+            }
 
             // gather the winning code (LDS row is [even k | odd k])
             const float *crow = cbs + (ro + bi) * S;
@@ -251,6 +275,7 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             }
         }
 
+        if (WANT_MARGIN && p.neartie && valid) p.neartie[item] = tie_bits;
         if (valid) {
             if (WANT_XQ) {
                 f32x4 *dst = reinterpret_cast<f32x4 *>(p.xq + item * E);
@@ -333,10 +358,10 @@ size_t rq_assign_workspace(int64_t n, int e, const int *K, int L)
     return 2 * resid + part;
 }
 
-template <int E, int THREADS, bool WANT_XQ>
+template <int E, int THREADS, bool WANT_XQ, bool WANT_MARGIN>
 static int launch_one(const RqParams &p, int grid, size_t lds, hipStream_t stream)
 {
-    auto kern = rq_assign_kernel<E, THREADS, WANT_XQ>;
+    auto kern = rq_assign_kernel<E, THREADS, WANT_XQ, WANT_MARGIN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(LCREC_EHIP, "rq_assign: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -345,23 +370,35 @@ static int launch_one(const RqParams &p, int grid, size_t lds, hipStream_t strea
     return check_launch("rq_assign_kernel");
 }
 
+template <int E, int THREADS>
+static int dispatch2(const RqParams &p, int grid, size_t lds, bool want_xq, hipStream_t stream)
+{
+    const bool want_margin = p.margin || p.neartie;
+    if (want_margin) return want_xq ? launch_one<E, THREADS, true, true>(p, grid, lds, stream)
+                                    : launch_one<E, THREADS, false, true>(p, grid, lds, stream);
+    return want_xq ? launch_one<E, THREADS, true, false>(p, grid, lds, stream)
+                   : launch_one<E, THREADS, false, false>(p, grid, lds, stream);
+}
+
 template <int E>
 static int dispatch(const RqParams &p, int threads, int grid, size_t lds, bool want_xq, hipStream_t stream)
 {
     if (threads == 512) {
         if constexpr (E == 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e=64 runs 256-thread workgroups");
-        else return want_xq ? launch_one<E, 512, true>(p, grid, lds, stream) : launch_one<E, 512, false>(p, grid, lds, stream);
+        else return dispatch2<E, 512>(p, grid, lds, want_xq, stream);
     }
-    return want_xq ? launch_one<E, 256, true>(p, grid, lds, stream) : launch_one<E, 256, false>(p, grid, lds, stream);
+    return dispatch2<E, 256>(p, grid, lds, want_xq, stream);
 }
 
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
               int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
+              float *margin_out, uint32_t *neartie_out, float tie_tau,
               void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     if (n == 0 && K && L >= 1 && L <= LCREC_MAX_LEVELS) return LCREC_OK;   // empty batch
     if (!z || !codebooks || !K || !idx_out) return fail(LCREC_EINVAL, "rq_assign: NULL pointer");
     if (n < 0 || L < 1 || L > LCREC_MAX_LEVELS) return fail(LCREC_EINVAL, "rq_assign: bad n=%lld or L=%d", (long long)n, L);
+    if (neartie_out && !(tie_tau >= 0.0f)) return fail(LCREC_EINVAL, "rq_assign: tie_tau must be >= 0");
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e_dim=%d (supported: 16, 32, 64)", e);
     if (((uintptr_t)z | (uintptr_t)codebooks | (uintptr_t)xq_out | (uintptr_t)resid_out) & 15)
         return fail(LCREC_EINVAL, "rq_assign: buffers must be 16-byte aligned");
@@ -407,6 +444,9 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
         p.xq = xq_out;
         p.resid_levels = resid_out;
         p.sse_partial = sse_out ? partial : nullptr;
+        p.margin = margin_out;
+        p.neartie = neartie_out;
+        p.tie_tau = tie_tau;
         float *next = nullptr;
         if (l1 < L) next = (zin == ping) ? pong : ping;
         p.resid_next = next;

@@ -697,7 +697,10 @@ __device__ unsigned long long g_sk_stamps[8];
 constexpr int SKP_THREADS = 512;
 constexpr int SKP_WAVES = SKP_THREADS / 64;
 constexpr int SKP_MAX_BLOCKS = 128;
-constexpr unsigned SKP_SPIN_LIMIT = 40u * 1000u * 1000u;     // ~ seconds of polling with s_sleep
+// One poll = s_sleep 1 + an L2 load, 0.3-1 us: the limit is ~0.1 s of waiting for ONE hand-over.  A spinning thread also
+// looks at *flag every 64 polls, so once any thread anywhere has timed out every other wait ends within microseconds and
+// the whole grid drains in about one limit, not one limit per remaining hand-over (iters x 2 per thread).
+constexpr unsigned SKP_SPIN_LIMIT = 200u * 1000u;
 constexpr unsigned long long SKP_EMPTY = ~0ull;               // exchange slot not written yet
 
 __device__ __forceinline__ void skp_put(double *slot, unsigned long long bits)
@@ -708,15 +711,22 @@ __device__ __forceinline__ unsigned long long skp_peek(const double *slot)
 {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the slot's value once it has one (bounded spin; on timeout *flag is set and whatever is there is returned)
-__device__ __forceinline__ double skp_take(const double *slot, unsigned long long first, unsigned *flag)
+// the slot's value once it has one.  Bounded: on timeout, or when another thread's timeout is seen in *flag, *flag is
+// set, `gave_up` becomes true and whatever is there is returned (the caller abandons the solve; outputs are poisoned).
+__device__ __forceinline__ double skp_take(const double *slot, unsigned long long first, unsigned *flag, bool &gave_up)
 {
     unsigned long long v = first;
     unsigned spins = 0;
     while (v == SKP_EMPTY) {
         __builtin_amdgcn_s_sleep(1);
         v = skp_peek(slot);
-        if (++spins > SKP_SPIN_LIMIT) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        ++spins;
+        if (v == SKP_EMPTY && ((spins & 63u) == 0u) &&
+            (spins > SKP_SPIN_LIMIT || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
+            break;
+        }
     }
     return __builtin_bit_cast(double, v);
 }
@@ -753,7 +763,12 @@ __device__ __forceinline__ void skp_grid_barrier(unsigned *counter, unsigned tar
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > SKP_SPIN_LIMIT) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            ++spins;
+            if (((spins & 63u) == 0u) &&
+                (spins > SKP_SPIN_LIMIT || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
         SK_STAMP(4);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -772,9 +787,12 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
     double *colacc = skp_sm + p.K;                    // [SKP_WAVES][K] (+ nblk: also the owner's gather buffer)
     __shared__ double wsum[SKP_WAVES];
     __shared__ double total_sh;
+    __shared__ int abort_sh;                          // a thread of this workgroup gave up a wait: leave the iteration loop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = p.K;
     const int64_t row0 = (int64_t)blockIdx.x * ROWS + wave * RW;
+    if (threadIdx.x == 0) abort_sh = 0;
+    bool gave_up = false;
     const double Bd = (double)p.B, Kd = (double)K;
     const ExactDiv divB(Bd), divK(Kd);
     unsigned phase = 0;
@@ -818,11 +836,12 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
         double s = 0.0;
         for (int b = 0; b < p.nblk; ++b) s += p.tot_part[b];
         total_sh = s;
+        if (__hip_atomic_load(p.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) abort_sh = 1;   // barrier timed out
     }
     __syncthreads();
     const double total = total_sh;
 
-    for (int it = 0; it < p.iters; ++it) {
+    for (int it = abort_sh ? p.iters : 0; it < p.iters; ++it) {
         SK_STAMP(7);
         if (it > 0) {                                            // re-arm the buffer of the NEXT iteration (see above)
             double *arm = p.col_part + ((size_t)((it + 1) % 3) * p.nblk + blockIdx.x) * K;
@@ -879,7 +898,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
         const double *pb = p.col_part + (size_t)(it % 3) * p.nblk * K + blockIdx.x;
         for (int i = threadIdx.x; i < owned * p.nblk; i += SKP_THREADS) {
             const double *slot = pb + (size_t)(i % p.nblk) * K + (i / p.nblk) * p.nblk;
-            colacc[i] = skp_take(slot, skp_peek(slot), p.flag);
+            colacc[i] = skp_take(slot, skp_peek(slot), p.flag, gave_up);
         }
         __syncthreads();
         SK_STAMP(2);
@@ -900,9 +919,11 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
         }
         SK_STAMP(3);
         // C: all K sums
-        for (int j = threadIdx.x; j < K; j += SKP_THREADS) colsum[j] = skp_take(fin + j, skp_peek(fin + j), p.flag);
+        for (int j = threadIdx.x; j < K; j += SKP_THREADS) colsum[j] = skp_take(fin + j, skp_peek(fin + j), p.flag, gave_up);
+        if (gave_up) abort_sh = 1;
         __syncthreads();
         SK_STAMP(6);
+        if (abort_sh) break;                                     // uniform: read after the barrier every thread passed
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -932,14 +953,41 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
     }
 }
 
+static size_t skp_lds_bytes(int K, int nblk) { return ((size_t)(1 + SKP_WAVES) * K + nblk) * sizeof(double); }
+
+// Whether all `nblk` workgroups of sk_persistent_kernel<CPL, RW> can be resident at once on the current device: the
+// kernel's hand-overs assume it (a workgroup that has not started cannot publish its sums).  Occupancy per CU for the
+// actual LDS size, as the runtime computes it from the kernel's registers and LDS, times the CU count; cached per
+// (variant, K, nblk).  Other work on the device can still hold CUs -- that case is what the bounded spins are for.
 template <int CPL, int RW>
-static void launch_skp(const SkPersist &p, hipStream_t stream)
+static bool skp_fits(int K, int nblk)
 {
-    const size_t lds = ((size_t)(1 + SKP_WAVES) * p.K + p.nblk) * sizeof(double);
-    if (lds > 48 * 1024)        // K = 1024: 75 KB (a failure here surfaces through check_launch at the caller)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sk_persistent_kernel<CPL, RW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static thread_local int cached_K = -1, cached_nblk = -1;
+    static thread_local bool cached = false;
+    if (K == cached_K && nblk == cached_nblk) return cached;
+    const size_t lds = skp_lds_bytes(K, nblk);
+    auto kern = sk_persistent_kernel<CPL, RW>;
+    bool ok = true;
+    if (lds > 48 * 1024)
+        ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    int per_cu = 0, cus = 0, dev = 0;
+    ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SKP_THREADS, lds) == hipSuccess &&
+         hipGetDevice(&dev) == hipSuccess &&
+         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+    (void)hipGetLastError();
+    cached = ok && (int64_t)per_cu * cus >= nblk;
+    cached_K = K;
+    cached_nblk = nblk;
+    return cached;
+}
+
+template <int CPL, int RW>
+static bool launch_skp(const SkPersist &p, hipStream_t stream)
+{
+    if (!skp_fits<CPL, RW>(p.K, p.nblk)) return false;           // caller falls back to the multi-launch solver
+    const size_t lds = skp_lds_bytes(p.K, p.nblk);
     hipLaunchKernelGGL((sk_persistent_kernel<CPL, RW>), dim3((unsigned)p.nblk), dim3(SKP_THREADS), lds, stream, p);
+    return true;
 }
 
 static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K, double eps, int iters,
@@ -984,13 +1032,14 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
         q.counter = minmax + 4; q.flag = minmax + 5;
         q.B = B; q.K = K; q.nblk = (int)nblk_p; q.iters = iters; q.eps = eps;
         q.idx_out = idx_out; q.idx_stride = idx_stride;
-        if (cpl <= 1) launch_skp<1, 4>(q, stream);
-        else if (cpl <= 2) launch_skp<2, 4>(q, stream);
-        else if (rw2) launch_skp<4, 2>(q, stream);
-        else if (cpl <= 4) launch_skp<4, 4>(q, stream);
-        else if (cpl <= 8) launch_skp<8, 2>(q, stream);
-        else launch_skp<16, 1>(q, stream);
-        return check_launch("sk_persistent_kernel");
+        bool launched;
+        if (cpl <= 1) launched = launch_skp<1, 4>(q, stream);
+        else if (cpl <= 2) launched = launch_skp<2, 4>(q, stream);
+        else if (rw2) launched = launch_skp<4, 2>(q, stream);
+        else if (cpl <= 4) launched = launch_skp<4, 4>(q, stream);
+        else if (cpl <= 8) launched = launch_skp<8, 2>(q, stream);
+        else launched = launch_skp<16, 1>(q, stream);
+        if (launched) return check_launch("sk_persistent_kernel");
     }
     hipLaunchKernelGGL(sk_init_kernel, dim3((unsigned)nblk), dim3(SK_THREADS), 0, stream, p);
     const size_t lds_iter = (size_t)(1 + SK_THREADS / 64) * K * sizeof(double);
@@ -1033,13 +1082,14 @@ static int launch_sk_small_e(int e, const float *r, const float *cb, int K, cons
 
 int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
                     int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                    hipStream_t stream)
+                    lcrec_context *ctx, hipStream_t stream)
 {
     if (n == 0 || G == 0) return LCREC_OK;
     if (!r || !cb || !offs || !idx_out) return fail(LCREC_EINVAL, "sinkhorn_assign: NULL pointer");
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "sinkhorn_assign: e_dim=%d (supported: 16, 32, 64)", e);
     if (G < 0 || K < 1 || iters < 1 || !(eps > 0)) return fail(LCREC_EINVAL, "sinkhorn_assign: bad G/K/iters/eps");
     if (G == 0) return LCREC_OK;
+    if (int rc = check_context(ctx, "sinkhorn_assign")) return rc;
     if (offs[0] < 0 || offs[G] > n) return fail(LCREC_EINVAL, "sinkhorn_assign: group offsets outside [0, n]");
     for (int g = 0; g < G; ++g)
         if (offs[g + 1] < offs[g]) return fail(LCREC_EINVAL, "sinkhorn_assign: group offsets not ascending");
@@ -1073,49 +1123,43 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
         }
     }
     if (!triples.empty()) {
-        hipError_t he = hipMemcpyAsync(triples_dev, triples.data(), sizeof(int64_t) * triples.size(), hipMemcpyHostToDevice, stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(stream);   // triples is a host temporary
+        // Group table -> device.  With a context it goes through the context's pinned ring (the copy reads pinned memory
+        // asynchronously; the slot is reused RING calls later), so the call returns without waiting; without one the
+        // table is a host temporary and the copy has to be waited for.
+        const size_t tbytes = sizeof(int64_t) * triples.size();
+        hipError_t he;
+        if (ctx) {
+            int slot = -1;
+            void *pin = ctx->ring_acquire(tbytes, &slot);
+            if (!pin) return LCREC_EHIP;
+            memcpy(pin, triples.data(), tbytes);
+            he = hipMemcpyAsync(triples_dev, pin, tbytes, hipMemcpyHostToDevice, stream);
+            ctx->ring_release(slot, stream);
+        } else {
+            he = hipMemcpyAsync(triples_dev, triples.data(), tbytes, hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(stream);
+        }
         if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn_assign: %s", hipGetErrorString(he));
         // The size classes are independent (disjoint rows of idx_out).  The slab launch is a hundred or so long-running
-        // workgroups; it goes to a helper stream forked from `stream` (and joined back below), so the tens of thousands of
-        // short workgroups of the LDS classes fill the CUs it leaves idle.
-        // Likewise the three larger LDS classes (thousands of mid-length workgroups, launches with long tails) go to a
-        // second helper stream beside the pair/triple class on the caller's: 20 rounds at 1 M items 148 -> 130-140 ms.
-        // LCREC_SK_SIDE2=0 keeps them on the caller's stream.
-        struct Side { hipStream_t s[2]; hipEvent_t fork, join[2]; };
-        static thread_local Side side[16] = {};
-        static const int side2 = [] { const char *e = getenv("LCREC_SK_SIDE2"); return e ? atoi(e) : 1; }();
-        int dev = 0;
+        // workgroups; with a context it goes to helper stream 0, forked from `stream` (and joined back on leaving this
+        // block), so the tens of thousands of short workgroups of the LDS classes fill the CUs it leaves idle.
+        // Likewise the three larger LDS classes (thousands of mid-length workgroups, launches with long tails) go to
+        // helper stream 1 beside the pair/triple class on the caller's: 20 rounds at 1 M items 148 -> 130-140 ms.
         const int n_lds = count[0] + count[1] + count[2] + count[3];
-        const bool can_fork = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
-        const bool fork_slab = can_fork && count[SK_SLAB] > 0 && n_lds > 0;
-        const bool fork_mid = can_fork && side2 && count[0] > 0 && (count[1] + count[2] + count[3]) > 0;
-        if ((fork_slab || fork_mid) && !side[dev].s[0]) {
-            bool ok = hipEventCreateWithFlags(&side[dev].fork, hipEventDisableTiming) == hipSuccess;
-            for (int i = 0; i < 2 && ok; ++i)
-                ok = hipStreamCreateWithFlags(&side[dev].s[i], hipStreamNonBlocking) == hipSuccess &&
-                     hipEventCreateWithFlags(&side[dev].join[i], hipEventDisableTiming) == hipSuccess;
-            if (!ok) return fail(LCREC_EHIP, "sinkhorn_assign: cannot create the helper streams");
+        const bool fork_slab = ctx && count[SK_SLAB] > 0 && n_lds > 0;
+        const bool fork_mid = ctx && count[0] > 0 && (count[1] + count[2] + count[3]) > 0;
+        if (fork_slab || fork_mid) {
+            if (int rc = ctx->ensure_streams()) return rc;
         }
-        if (fork_slab || fork_mid) (void)hipEventRecord(side[dev].fork, stream);
-        if (fork_slab) (void)hipStreamWaitEvent(side[dev].s[0], side[dev].fork, 0);
-        if (fork_mid) (void)hipStreamWaitEvent(side[dev].s[1], side[dev].fork, 0);
+        ForkJoin fj(ctx, stream, (fork_slab ? 1u : 0u) | (fork_mid ? 2u : 0u));
         const int64_t *t = triples_dev;
         for (int cls = 0; cls < NCLS; ++cls) {
             if (!count[cls]) continue;
-            hipStream_t on = cls == SK_SLAB ? (fork_slab ? side[dev].s[0] : stream) : (cls > 0 && fork_mid ? side[dev].s[1] : stream);
+            hipStream_t on = cls == SK_SLAB ? fj.on(0) : (cls > 0 ? fj.on(1) : stream);
             int rc = cls == SK_SLAB ? launch_sk_small_e<true>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, qslab, on)
                                     : launch_sk_small_e<false>(e, r, cb, K, t, count[cls], maxg[cls], eps, iters, idx_out, idx_stride, nullptr, on);
             if (rc) return rc;
             t += (size_t)3 * count[cls];
-        }
-        if (fork_slab) {
-            (void)hipEventRecord(side[dev].join[0], side[dev].s[0]);
-            (void)hipStreamWaitEvent(stream, side[dev].join[0], 0);
-        }
-        if (fork_mid) {
-            (void)hipEventRecord(side[dev].join[1], side[dev].s[1]);
-            (void)hipStreamWaitEvent(stream, side[dev].join[1], 0);
         }
     }
     // larger problems (a training batch) go through the multi-launch path, one at a time

@@ -95,6 +95,15 @@ class DistContext:
         tdist.all_reduce(flat, op=tdist.ReduceOp.SUM)
         return flat[:-1] / flat[-1]
 
+    def sum_int(self, value):
+        """Sum of a Python int over the ranks."""
+        if not self.enabled:
+            return int(value)
+        dev = self.device if (self.device is not None and tdist.get_backend() != "gloo") else "cpu"
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+        return int(t.item())
+
     def all_reduce_sum_(self, *tensors):
         if not self.enabled:
             return

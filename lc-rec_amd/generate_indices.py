@@ -118,23 +118,30 @@ def build_model_from_args(args, in_dim):
 
 
 @torch.no_grad()
-def assign_all(model, data, chunk_rows=1 << 20):
-    """Pass 1 (:77-95): int64 [N, L] hard indices plus the residual entering the last level."""
+def assign_all(model, data, chunk_rows=1 << 20, audit=None):
+    """Pass 1 (:77-95): int64 [N, L] hard indices plus the residual entering the last level.
+    audit: optional dict; receives "neartie" (int32 [N], ops.NEARTIE_TAU) -- the near-tie flags of pass 1."""
     levels = list(model.rq.vq_layers)
     Ws, bs, scs, shs = model.encoder.folded()
     cbs = [q.embedding.weight.detach() for q in levels]
     flat, ks = ops.flatten_codebooks(cbs)
-    idx_parts, last_parts = [], []
+    idx_parts, last_parts, tie_parts = [], [], []
     for lo in range(0, data.shape[0], chunk_rows):
         x = data[lo:lo + chunk_rows]
-        idx, latent, _, _ = ops.encode_assign(x, Ws, bs, flat, ks, scs, shs, want_latent=True)
+        a = {} if audit is not None else None
+        idx, latent, _, _ = ops.encode_assign(x, Ws, bs, flat, ks, scs, shs, want_latent=True, audit=a,
+                                              tie_tau=ops.NEARTIE_TAU)
         idx_parts.append(idx)
+        if a is not None:
+            tie_parts.append(a["neartie"])
         if len(levels) > 1:
             pflat, pks = ops.flatten_codebooks(cbs[:-1])
             _, _, _, resid = ops.rq_assign(latent, pflat, pks, want_resid=True)
             last_parts.append(resid[len(levels) - 1].clone())
         else:
             last_parts.append(latent)
+    if audit is not None:
+        audit["neartie"] = torch.cat(tie_parts) if tie_parts else torch.zeros(0, dtype=torch.int32, device=data.device)
     return torch.cat(idx_parts), torch.cat(last_parts), ks
 
 
@@ -246,8 +253,12 @@ def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=Tr
     model = model.to(torch.device(device)).eval()
     if verbose:
         print(model)
-    idx, resid_last, ks = sharded_assign(ctx, data, lambda x: assign_all(model, x), device)
+    audit = {}
+    idx, resid_last, ks = sharded_assign(ctx, data, lambda x: assign_all(model, x, audit=audit), device)
     first_pass = idx.clone()
+    # near-tie audit of pass 1: items whose two best codes at some level are closer than the rounding noise of
+    # vq.py:71-73 -- the only ones a CPU run of the reference could index differently (ops.NEARTIE_TAU)
+    neartie_items = int(ctx.sum_int(int((audit["neartie"] != 0).sum())))
 
     def show(round_no, n_groups):
         if verbose:
@@ -258,7 +269,11 @@ def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=Tr
     final = ops.collision_groups(idx, ks, want_groups=False)
     n = idx.shape[0]
     stats = {"items": n, "max_conflicts": final["max_count"], "collision_rate": (n - final["unique"]) / n if n else 0.0,
-             "rounds": len(history), "groups_per_round": history}
+             "rounds": len(history), "groups_per_round": history, "neartie_items": neartie_items,
+             "neartie_tau": ops.NEARTIE_TAU}
+    if lead:
+        log.info("near-tie items in pass 1: %d of %d (top-2 code gap <= %.3g x distance magnitude at some level); only "
+                 "these could receive a different tuple from a CPU run of the reference", neartie_items, n, ops.NEARTIE_TAU)
     if verbose:
         print("All indices number: ", n)
         print("Max number of conflicts: ", stats["max_conflicts"])

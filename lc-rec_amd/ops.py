@@ -14,6 +14,13 @@ from . import _lib
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _workspaces = {}
 
+# Default threshold of the near-tie audit (lcrec_rq_assign's tie_tau): a level is flagged when its top-2 distance gap is
+# <= NEARTIE_TAU * (xx + cc[idx]).  Measured, not derived (oracle/neartie_audit.py, tests/golden/f9_neartie_*.npz): on
+# 1 M x 768-d items 33 tuples differ between the reference's CPU ops (batch 64 or 4096; the two batch sizes differ from
+# EACH OTHER on 9) and this library's canonical order, the worst of them at a relative gap of 2.5e-6; 2^-17 covers that
+# with a power of two of slack and flags 995 of the 1 M items (0.1 %).  On the Games shape (16 859 x 4096-d) 0 differ.
+NEARTIE_TAU = 2.0 ** -17
+
 
 # Host cost matters: a training step makes ~50 calls into the library, and torch.cuda.current_stream() /
 # torch.cuda.device() cost 5-10 us each (Stream objects, index normalisation) -- as much as the launch itself.
@@ -79,6 +86,62 @@ def release_workspaces():
     _workspaces.clear()
 
 
+# One lcrec_context per device (include/lcrec.h): the library's helper streams, their events and the pinned upload ring.
+# Created on first use by the two calls that can overlap launches, destroyed at interpreter exit / release_contexts().
+_contexts = {}
+_pipelines = 2
+
+
+def _context(device):
+    ctx = _contexts.get(device.index)
+    if ctx is None:
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        with _on(device):
+            _lib.check(lib.lcrec_context_create(ctypes.byref(h)), "lcrec_context_create")
+        _lib.check(lib.lcrec_context_set_pipelines(h, _pipelines), "lcrec_context_set_pipelines")
+        ctx = _contexts[device.index] = h
+    return ctx
+
+
+def set_pipelines(n):
+    """Chunk pipelines of encode_assign (lcrec_context_set_pipelines): 1 = everything on the current stream, 2 = default."""
+    global _pipelines
+    n = int(n)
+    if n not in (1, 2):
+        raise _lib.LcrecError("pipelines must be 1 or 2")
+    _pipelines = n
+    for h in _contexts.values():
+        _lib.check(_lib.load().lcrec_context_set_pipelines(h, n), "lcrec_context_set_pipelines")
+
+
+def release_contexts():
+    """Drain and destroy the library's helper streams (lcrec_context_destroy)."""
+    while _contexts:
+        _, h = _contexts.popitem()
+        try:
+            _lib.load().lcrec_context_destroy(h)
+        except Exception:          # interpreter shutdown: the runtime may already be gone
+            pass
+
+
+import atexit  # noqa: E402
+atexit.register(release_contexts)
+
+
+def _audit_buffers(audit, tie_tau, n, L, dev):
+    """(margin tensor | None, neartie tensor | None, tau) for the near-tie audit outputs of lcrec_rq_assign."""
+    if audit is None:
+        return None, None, 0.0
+    margin = torch.empty((n, L), dtype=torch.float32, device=dev)
+    neartie = torch.zeros(n, dtype=torch.int32, device=dev) if tie_tau is not None else None
+    audit["margin"] = margin
+    if neartie is not None:
+        audit["neartie"] = neartie           # bit l: level l's top-2 gap <= tie_tau * (xx + cc[idx])
+        audit["tie_tau"] = float(tie_tau)
+    return margin, neartie, float(tie_tau or 0.0)
+
+
 def linear_forward(x, weight, bias=None, bn_scale=None, bn_shift=None, relu=False):
     """y = [relu]([bn](x @ weight.T + bias)) -- one group of MLPLayers.forward (layers.py:18-30,42)."""
     lib = _lib.load()
@@ -132,10 +195,13 @@ def flatten_codebooks(codebooks):
     return flat, ks
 
 
-def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=False, xq_init=None):
+def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=False, xq_init=None, audit=None,
+              tie_tau=None):
     """ResidualVectorQuantizer.forward values with use_sk=False (rq.py:39-55).
 
     xq_init: optional [n, e] tensor that the x_q sum starts from (it is updated in place and returned).
+    audit: optional dict that receives the near-tie audit outputs (include/lcrec.h): "margin" float32 [n, L] (top-2
+    distance gap per level) and, with tie_tau, "neartie" int32 [n] (bit l set = level l is a near tie under tie_tau).
     Returns (idx int64 [n, L], xq [n, e] | None, sse float64 [L] | None, resid [L+1, n, e] | None);
     resid[l] is the residual entering level l, resid[L] the residual left after the last level."""
     lib = _lib.load()
@@ -153,19 +219,22 @@ def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=F
         xq = torch.empty((n, e), dtype=torch.float32, device=dev) if want_xq else None
     sse = torch.zeros(L, dtype=torch.float64, device=dev) if want_sse else None
     resid = torch.empty((L + 1, n, e), dtype=torch.float32, device=dev) if want_resid else None
+    margin, neartie, tau = _audit_buffers(audit, tie_tau, n, L, dev)
     karr = _ints(ks)
     with _on(dev):
         nbytes = lib.lcrec_rq_assign_workspace(n, e, karr, L)
         ws = _workspace(nbytes, dev)
         rc = lib.lcrec_rq_assign(_ptr(z), n, e, _ptr(cb), karr, L, _ptr(idx), _ptr(xq), int(xq_init is not None),
-                                 _ptr(sse), _ptr(resid), _ptr(ws), ws.numel(), _stream_ptr())
+                                 _ptr(sse), _ptr(resid), _ptr(margin), _ptr(neartie), tau, _ptr(ws), ws.numel(),
+                                 _stream_ptr())
     _lib.check(rc, "lcrec_rq_assign")
     return idx, xq, sse, resid
 
 
 def encode_assign(x, weights, biases, codebooks_flat, ks, bn_scales=None, bn_shifts=None, want_latent=False,
-                  want_xq=False, want_sse=False):
+                  want_xq=False, want_sse=False, audit=None, tie_tau=None):
     """RQVAE.get_indices(xs, use_sk=False) (rqvae.py:68-72): encoder MLP + L-level argmin assignment.
+    audit / tie_tau: as rq_assign (near-tie audit of the quantiser).
 
     weights[l] is nn.Linear.weight of encoder layer l ([out_l, in_l]); bn_scales/bn_shifts are
     per-layer folded eval-mode BatchNorm affines or None.
@@ -195,11 +264,13 @@ def encode_assign(x, weights, biases, codebooks_flat, ks, bn_scales=None, bn_shi
     scp = PA(*[0 if t is None else t.data_ptr() for t in scs])
     shp = PA(*[0 if t is None else t.data_ptr() for t in shs])
     darr, karr = _ints(dims), _ints(ks)
+    margin, neartie, tau = _audit_buffers(audit, tie_tau, n, L, dev)
     with _on(dev):
         nbytes = lib.lcrec_encode_assign_workspace(n, darr, nl, karr, L)
         ws = _workspace(nbytes, dev)
         rc = lib.lcrec_encode_assign(_ptr(x), n, darr, nl, wp, bp, scp, shp, _ptr(cb), karr, L, _ptr(idx),
-                                     _ptr(latent), _ptr(xq), _ptr(sse), _ptr(ws), ws.numel(), _stream_ptr())
+                                     _ptr(latent), _ptr(xq), _ptr(sse), _ptr(margin), _ptr(neartie), tau, _ptr(ws),
+                                     ws.numel(), _context(dev), _stream_ptr())
     _lib.check(rc, "lcrec_encode_assign")
     return idx, latent, xq, sse
 
@@ -232,7 +303,7 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
         nbytes = lib.lcrec_sinkhorn_assign_workspace(n, K, oarr, G)
         ws = _workspace(nbytes, resid.device)
         rc = lib.lcrec_sinkhorn_assign(_ptr(resid), n, e, _ptr(codebook), K, oarr, G, float(epsilon), int(iters),
-                                       _ptr(out), stride, _ptr(ws), ws.numel(), _stream_ptr())
+                                       _ptr(out), stride, _ptr(ws), ws.numel(), _context(resid.device), _stream_ptr())
     _lib.check(rc, "lcrec_sinkhorn_assign")
     if G > 0 and int(np.diff(offs).max()) * K > 16384:
         # the one-launch solver for batch-sized problems poisons its output with -1 if its (bounded)

@@ -60,6 +60,23 @@ class RQVAE(nn.Module):
         _, _, indices = self.rq(x_e, use_sk=use_sk, use_ema=False)
         return indices
 
+    @torch.no_grad()
+    def get_indices_audited(self, xs, tie_tau=None):
+        """get_indices(xs, use_sk=False) plus the near-tie audit of the quantiser (include/lcrec.h, lcrec_rq_assign):
+        returns (indices int64 [n, L], neartie int32 [n], margin float32 [n, L]).  Bit l of neartie[i] is set when the
+        two best codes of item i at level l are closer than tie_tau * (xx + cc) -- the rows on which the reference's own
+        CPU arithmetic (vq.py:71-75, summation order unspecified) may choose differently; all other rows carry the
+        reference's tuple (measured rates: ops.NEARTIE_TAU).  Eval mode, 2-d input, ReLU encoder."""
+        if self.training or xs.dim() != 2 or not self.encoder.fusable():
+            raise ops._lib.LcrecError("get_indices_audited: eval mode, a 2-d batch and a ReLU encoder are required")
+        levels = list(self.rq.vq_layers)
+        Ws, bs, scs, shs = self.encoder.folded()
+        flat, ks = ops.flatten_codebooks([q.embedding.weight.detach() for q in levels])
+        audit = {}
+        idx = ops.encode_assign(xs, Ws, bs, flat, ks, scs, shs, audit=audit,
+                                tie_tau=ops.NEARTIE_TAU if tie_tau is None else tie_tau)[0]
+        return idx, audit["neartie"], audit["margin"]
+
     def compute_loss(self, out, quant_loss, xs=None):
         if self.loss_type == "mse":
             loss_recon = F.mse_loss(out, xs, reduction="mean")

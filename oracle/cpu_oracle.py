@@ -25,7 +25,8 @@ def build():
 
 
 def _load():
-    if not os.path.exists(_SO):
+    src = os.path.join(_HERE, "lcrec_oracle.c")
+    if not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
         build()
     lib = ctypes.CDLL(_SO)
     lib.lcrec_oracle_linear.restype = ctypes.c_int
@@ -38,6 +39,10 @@ def _load():
     lib.lcrec_oracle_encode_assign.argtypes = [
         _f32p, ctypes.c_int64, _i32p, ctypes.c_int, ctypes.POINTER(_f32p), ctypes.POINTER(_f32p),
         ctypes.POINTER(_f32p), ctypes.POINTER(_f32p), _f32p, _i32p, ctypes.c_int, _i64p, _f32p, _f32p, _f64p]
+    lib.lcrec_oracle_rq_assign_m.restype = ctypes.c_int
+    lib.lcrec_oracle_rq_assign_m.argtypes = lib.lcrec_oracle_rq_assign.argtypes + [_f32p, _f32p]
+    lib.lcrec_oracle_encode_assign_m.restype = ctypes.c_int
+    lib.lcrec_oracle_encode_assign_m.argtypes = lib.lcrec_oracle_encode_assign.argtypes + [_f32p, _f32p]
     lib.lcrec_oracle_code_stats.restype = ctypes.c_int
     lib.lcrec_oracle_code_stats.argtypes = [_i64p, ctypes.c_int64, _f32p, ctypes.c_int64, ctypes.c_int,
                                             ctypes.c_int, _f32p, _f32p]
@@ -99,7 +104,7 @@ def linear(x, W, b=None, bn_scale=None, bn_shift=None, relu=False, threads=1):
     return y
 
 
-def rq_assign(z, codebooks, want_resid=False):
+def rq_assign(z, codebooks, want_resid=False, want_margin=False):
     """rq.py:39-55 over vq.py:63-99 (argmin branch).
 
     codebooks: list of [K_l, e] arrays.  Returns dict(idx, xq, sse[, resid])."""
@@ -112,16 +117,20 @@ def rq_assign(z, codebooks, want_resid=False):
     xq = np.empty((n, e), dtype=np.float32)
     sse = np.zeros(L, dtype=np.float64)
     resid = np.empty((L + 1, n, e), dtype=np.float32) if want_resid else None
-    rc = lib().lcrec_oracle_rq_assign(_p(z), n, e, _p(cb), _p(Ks, _i32p), L, _p(idx, _i64p), _p(xq), _p(sse, _f64p),
-                                      _p(resid))
+    margin = np.empty((n, L), dtype=np.float32) if want_margin else None
+    scale = np.empty((n, L), dtype=np.float32) if want_margin else None
+    rc = lib().lcrec_oracle_rq_assign_m(_p(z), n, e, _p(cb), _p(Ks, _i32p), L, _p(idx, _i64p), _p(xq), _p(sse, _f64p),
+                                        _p(resid), _p(margin), _p(scale))
     assert rc == 0, rc
     out = {"idx": idx, "xq": xq, "sse": sse}
+    if want_margin:
+        out["margin"], out["scale"] = margin, scale
     if want_resid:
         out["resid"] = resid
     return out
 
 
-def encode_assign(x, weights, biases, codebooks, bn_scale=None, bn_shift=None, threads=1):
+def encode_assign(x, weights, biases, codebooks, bn_scale=None, bn_shift=None, threads=1, want_margin=False):
     """rqvae.py:68-72 (get_indices, use_sk=False).  weights[l] is [out_l, in_l]."""
     x = _f32(x)
     n = x.shape[0]
@@ -143,13 +152,17 @@ def encode_assign(x, weights, biases, codebooks, bn_scale=None, bn_shift=None, t
     idx = np.empty((n, L), dtype=np.int64)
     lat = np.empty((n, e), dtype=np.float32)
     xq = np.empty((n, e), dtype=np.float32)
+    margin = np.empty((n, L), dtype=np.float32) if want_margin else None
+    scale = np.empty((n, L), dtype=np.float32) if want_margin else None
     sses = []
 
     def run(lo, hi):
         sse = np.zeros(L, dtype=np.float64)
-        rc = lib().lcrec_oracle_encode_assign(_p(x[lo:hi]), hi - lo, _p(dims, _i32p), nl, Wp, bp, scp, shp, _p(cb),
-                                              _p(Ks, _i32p), L, _p(idx[lo:hi], _i64p), _p(lat[lo:hi]),
-                                              _p(xq[lo:hi]), _p(sse, _f64p))
+        rc = lib().lcrec_oracle_encode_assign_m(_p(x[lo:hi]), hi - lo, _p(dims, _i32p), nl, Wp, bp, scp, shp, _p(cb),
+                                                _p(Ks, _i32p), L, _p(idx[lo:hi], _i64p), _p(lat[lo:hi]),
+                                                _p(xq[lo:hi]), _p(sse, _f64p),
+                                                _p(margin[lo:hi]) if want_margin else None,
+                                                _p(scale[lo:hi]) if want_margin else None)
         assert rc == 0, rc
         sses.append((lo, sse))
 
@@ -163,7 +176,10 @@ def encode_assign(x, weights, biases, codebooks, bn_scale=None, bn_shift=None, t
     sse = np.zeros(L, dtype=np.float64)
     for _, s in sorted(sses, key=lambda t: t[0]):
         sse += s
-    return {"idx": idx, "latent": lat, "xq": xq, "sse": sse}
+    out = {"idx": idx, "latent": lat, "xq": xq, "sse": sse}
+    if want_margin:
+        out["margin"], out["scale"] = margin, scale
+    return out
 
 
 def code_stats(idx_col, resid, K):

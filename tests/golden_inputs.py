@@ -110,3 +110,25 @@ def toy_items(seed, n=3000, d=128):
     x[1200] = x[5]
     x[2999] = x[2998]
     return x
+
+
+# ---------------------------------------------------------------- F9: near-tie audit at bench scale
+NEARTIE_CASES = {"c3": (1_000_000, 768), "c2": (16_859, 4096)}   # BASELINE.json configs[2], configs[1]
+
+
+def neartie_items(n, in_dim, seed=900, chunk=65536):
+    """[n, in_dim] fp32 N(0,1) items, generated a chunk at a time (PCG64 float32 ziggurat: 768 M values in a
+    few seconds).  numpy does not freeze Generator streams across versions, so the fixture stores a sha256 of
+    the first chunk and the test refuses to run on a drifted stream instead of reporting false mismatches."""
+    g = np.random.Generator(np.random.PCG64(seed + in_dim))
+    x = np.empty((n, in_dim), dtype=np.float32)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        x[lo:lo + m] = g.standard_normal((m, in_dim), dtype=np.float32)
+    return x
+
+
+def neartie_encoder(in_dim, e=32, seed=900):
+    dims = [in_dim] + RUN_SH_LAYERS + [e]
+    Ws, bs, _ = encoder_weights(dims, seed)
+    return dims, Ws, bs

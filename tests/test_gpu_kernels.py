@@ -99,6 +99,18 @@ def test_rq_assign_bit_exact(hip, oracle, n, e, Ks):
     # the index-only variant (no x_q registers) must agree
     idx2, _, _, _ = hip.ops.rq_assign(torch.from_numpy(z).to(dev), flat, ks)
     assert torch.equal(idx2, idx)
+    # near-tie audit outputs: the top-2 gap per level is the oracle's bit for bit, and the flag word is
+    # margin <= tau * (xx + cc[idx]) in fp32 -- also when the levels are split over several launches (8 x 1024)
+    wm = oracle.rq_assign(z, cbs, want_margin=True)
+    for tau in (2.0 ** -17, 0.05):
+        audit = {}
+        idx3, xq3, _, _ = hip.ops.rq_assign(torch.from_numpy(z).to(dev), flat, ks, want_xq=True, audit=audit, tie_tau=tau)
+        assert torch.equal(idx3, idx) and torch.equal(xq3, xq)
+        assert np.array_equal(audit["margin"].cpu().numpy(), wm["margin"])
+        flags = (wm["margin"] <= np.float32(tau) * wm["scale"])
+        want_bits = (flags.astype(np.int64) << np.arange(len(Ks))).sum(1).astype(np.int32)
+        assert np.array_equal(audit["neartie"].cpu().numpy(), want_bits)
+    assert (want_bits != 0).any() or n < 64                       # tau = 0.05 does flag rows on these inputs
 
 
 def test_rq_assign_exact_ties_take_first_index(hip, oracle):
@@ -118,6 +130,14 @@ def test_rq_assign_exact_ties_take_first_index(hip, oracle):
     idx, _, _, _ = hip.ops.rq_assign(torch.from_numpy(z).to(dev), flat, ks)
     assert np.array_equal(idx.cpu().numpy(), want["idx"])
     assert not np.isin(idx.cpu().numpy()[:, 0], [100, 200, 37]).any()
+    # an exact tie has margin 0 and is flagged under any tau, 0 included
+    audit = {}
+    hip.ops.rq_assign(torch.from_numpy(z).to(dev), flat, ks, audit=audit, tie_tau=0.0)
+    wm = oracle.rq_assign(z, [cb, cb], want_margin=True)
+    assert np.array_equal(audit["margin"].cpu().numpy(), wm["margin"])
+    tied = np.isin(want["idx"][:, 0], [5, 36])
+    assert tied.any() and (audit["margin"].cpu().numpy()[tied, 0] == 0).all()
+    assert ((audit["neartie"].cpu().numpy()[tied] & 1) == 1).all()
 
 
 @pytest.mark.parametrize("n,dims,Ks,bn", [

@@ -148,3 +148,20 @@ def test_torch_ref_train_step_matches_reference(bn):
     for k in g.files:
         if k.startswith("grad__"):
             np.testing.assert_allclose(leaf[k[6:]].grad.numpy(), g[k], rtol=1e-4, atol=1e-7, err_msg=k)
+
+
+def test_neartie_fixture_c2_is_what_the_oracle_computes(oracle):
+    """F9 (oracle/neartie_audit.py): on the Games-shaped inputs the oracle reproduces the recorded index-matrix hash
+    and the recorded number of near-tie rows, and that hash is also the reference's (0 differing rows at this shape).
+    The C3 fixture (1 M rows) is replayed on the GPU only (tests/test_gpu_neartie.py)."""
+    import hashlib
+    f = gold("f9_neartie_c2.npz")
+    n, in_dim = gi.NEARTIE_CASES["c2"]
+    x = gi.neartie_items(n, in_dim)
+    assert hashlib.sha256(x[:65536].tobytes()).hexdigest() == str(f["sha_x_head"])
+    dims, Ws, bs = gi.neartie_encoder(in_dim)
+    o = oracle.encode_assign(x, Ws, bs, list(f["codebooks"]), threads=8, want_margin=True)
+    sha = hashlib.sha256(np.ascontiguousarray(o["idx"], dtype=np.int16).tobytes()).hexdigest()
+    assert sha == str(f["sha_oracle"]) == str(f["sha_ref4096"]) == str(f["sha_ref64"])
+    flagged = (o["margin"] <= np.float32(f["tau"]) * o["scale"]).any(1)
+    assert int(flagged.sum()) == int(f["flagged_count"]) and len(f["rows"]) == 0

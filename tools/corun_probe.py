@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do two streams of persistent GEMM launches that share the CUs hurt each other?
 
-Two lcrec_encode_assign calls (one chunk pipeline each, LCREC_ENC_STREAMS=1), 524 288 items each: first one after the
+Two lcrec_encode_assign calls (one chunk pipeline each, ops.set_pipelines(1)), 524 288 items each: first one after the
 other on one stream, then at the same time on two streams.  The tiles of a persistent launch are dealt statically over
 256 workgroups, so a launch that gets only part of the CUs runs in extra partial rounds.
 """
@@ -9,7 +9,6 @@ import os
 import sys
 import time
 
-os.environ["LCREC_ENC_STREAMS"] = "1"
 import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +18,7 @@ from lcrec_amd import ops  # noqa: E402
 
 def main():
     dev = "cuda:0"
+    ops.set_pipelines(1)
     torch.manual_seed(1)
     model = lcrec_amd.RQVAE(in_dim=768, num_emb_list=[256] * 4, e_dim=32, layers=[2048, 1024, 512, 256, 128, 64],
                             kmeans_init=False, sk_epsilons=[0.0] * 4, sk_iters=50).to(dev).eval()
