@@ -60,13 +60,18 @@ def synth_model(in_dim, device, seed=2024, codes=None):
         std = (2.0 / (dims[l] + dims[l + 1])) ** 0.5
         Ws.append(torch.randn((dims[l + 1], dims[l]), generator=g, device=device, dtype=torch.float32) * std)
         bs.append(torch.zeros(dims[l + 1], device=device, dtype=torch.float32))
-    probe = torch.randn((8192, in_dim), generator=g, device=device, dtype=torch.float32)
+    probe = torch.randn((16384, in_dim), generator=g, device=device, dtype=torch.float32)
     z = probe
     for l in range(len(Ws)):
         z = lcrec_amd.ops.linear_forward(z, Ws[l], bs[l], relu=l != len(Ws) - 1)
     cbs, resid = [], z
+    unused = torch.ones(resid.shape[0], dtype=torch.bool, device=device)
     for K in (codes or CODES):
-        pick = torch.randperm(resid.shape[0], generator=g, device=device)[:K]
+        # a row that already served as a code has residual exactly 0: drawing it again would put duplicate all-zero
+        # codes into the deeper codebooks (exact ties for every item near them), which no k-means init produces
+        perm = torch.randperm(resid.shape[0], generator=g, device=device)
+        pick = perm[unused[perm]][:K]
+        unused[pick] = False
         cbs.append(resid[pick].clone())
         flat, ks = lcrec_amd.ops.flatten_codebooks(cbs)
         _, xq, _, _ = lcrec_amd.ops.rq_assign(z, flat, ks, want_xq=True)
