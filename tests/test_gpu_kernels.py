@@ -217,12 +217,17 @@ def test_sinkhorn_golden_fixture(hip):
         g = np.load(os.path.join(gold, f"f3_sinkhorn_{B}.npz"))
         z, cb = gi.sinkhorn_case(B)
         got = hip.ops.sinkhorn_assign(torch.from_numpy(z).to(dev), torch.from_numpy(cb).to(dev), 0.003, 50).cpu().numpy()
-        bad = got != g["idx"].astype(np.int64)
-        # The reference's own fp32 distances (MKL summation order) differ from the canonical chains by
-        # ~1e-7 relative; exp(-d/0.003) amplifies that to ~1e-4 in Q, so only rows whose reference top-2
-        # margin is above that are pinned.  (Against the canonical-order oracle the bound is 1e-9, above.)
-        assert not (bad & (g["margin"] > 1e-3)).any()
-        assert bad.mean() < 5e-3
+        bad = np.flatnonzero(got != g["idx"].astype(np.int64))
+        # The reference's own fp32 distances (MKL summation order) differ from the canonical chains by ~1e-7 relative
+        # and exp(-d/0.003) amplifies that, so rows with a near-tied argmax could flip.  oracle/make_golden.py recorded
+        # the exact set of rows on which the reference's fp64 solve over CANONICAL-order distances differs from the
+        # reference (`canonical_differ_rows`: empty for both fixtures).  The GPU may differ from the reference only there,
+        # or where the canonical solve's own top-2 margin is inside the 1e-9 the multi-workgroup association allows (no row of
+        # the 2048-row fixture: its smallest margin is 5.9e-3) -- so both fixtures are pinned row for row.
+        allowed = set(g["canonical_differ_rows"].tolist())
+        if B > 8:     # (8 rows x 256 columns saturates: every row's top-2 entries of Q are exactly tied in the reference too)
+            allowed |= set(np.flatnonzero(g["canonical_margin"] <= 1e-9).tolist())
+        assert set(bad.tolist()) <= allowed, (B, sorted(set(bad.tolist()) - allowed))
 
 
 @pytest.mark.parametrize("K,e", [(256, 32), (16, 16), (1024, 32)])
