@@ -244,7 +244,7 @@ def kmeans(samples, num_clusters, num_iters=10):
 def kmeans_pp_seed(x, num_clusters, generator=None):
     """k-means++ seeding on the device: the first centre uniformly, every next one with probability
     proportional to the squared distance to the nearest centre chosen so far (one draw per centre; sklearn's
-    greedy variant tries 2 + log K candidates per centre).  All draws come from `generator` (a device
+    greedy variant tries 2 + log K candidates per centre).  No host synchronisation: K draws are K queued launches.  All draws come from `generator` (a device
     generator; default: one seeded from torch's global CPU generator, so torch.manual_seed governs it)."""
     n = x.shape[0]
     if generator is None:
@@ -255,8 +255,8 @@ def kmeans_pp_seed(x, num_clusters, generator=None):
     nearest = ((x - x[first]) ** 2).sum(1)
     for _ in range(1, num_clusters):
         w = nearest.clamp_min(0)
-        if float(w.sum()) <= 0:                 # fewer distinct points than clusters: fall back to uniform
-            w = torch.ones_like(w)
+        # fewer distinct points than clusters: fall back to uniform -- decided on the device, no host round trip per centre
+        w = torch.where(w.sum() > 0, w, torch.ones_like(w))
         nxt = torch.multinomial(w, 1, generator=generator)
         picks.append(nxt)
         nearest = torch.minimum(nearest, ((x - x[nxt]) ** 2).sum(1))

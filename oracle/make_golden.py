@@ -501,6 +501,30 @@ def fixture_trainer(manifest):
                 "(transformers), main.py:14-49 CLI defaults and the type=bool quirk"}
 
 
+# --------------------------------------------------------------------------- F10
+def fixture_kmeans(ref, manifest):
+    """The reference's kmeans() (index/models/layers.py:69-82: sklearn KMeans(n_clusters, max_iter).fit on the host,
+    k-means++ seeded from numpy's GLOBAL RNG) under np.random.seed: pins the host path of lcrec_amd.layers.kmeans for the
+    scikit-learn version present (recorded; the reference pins none)."""
+    import sklearn
+    x = gi.kmeans_case()
+    out = {}
+    for K, iters in ((256, 10), (64, 100)):
+        np.random.seed(2024)
+        c = ref["layers"].kmeans(t(x), K, iters)
+        assert c.dtype == torch.float32 and tuple(c.shape) == (K, x.shape[1])
+        np.random.seed(2024)
+        again = ref["layers"].kmeans(t(x), K, iters)
+        out[f"centres_{K}_{iters}"] = c.numpy()
+        out[f"rerun_max_abs_diff_{K}_{iters}"] = np.float32((c - again).abs().max())
+    name = save("f10_kmeans.npz", **out)
+    manifest["fixtures"][name] = {
+        "pins": "layers.py:69-82 kmeans() = sklearn KMeans(n_clusters, max_iter).fit, numpy global RNG seeded 2024",
+        "inputs": "golden_inputs.kmeans_case(); np.random.seed(2024) before each call",
+        "sklearn": sklearn.__version__,
+        "rerun_max_abs_diff": float(max(out[k] for k in out if k.startswith("rerun")))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -521,6 +545,9 @@ def main():
         if want is None or name in want:
             print("generating", name, flush=True)
             fn()
+    if want is None or "kmeans" in want:
+        print("generating kmeans", flush=True)
+        fixture_kmeans(ref, manifest)
     if want is None or "generate" in want:
         print("generating generate", flush=True)
         fixture_generate(load_reference("index"), manifest)

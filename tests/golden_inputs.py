@@ -132,3 +132,11 @@ def neartie_encoder(in_dim, e=32, seed=900):
     dims = [in_dim] + RUN_SH_LAYERS + [e]
     Ws, bs, _ = encoder_weights(dims, seed)
     return dims, Ws, bs
+
+
+# ---------------------------------------------------------------- F10: k-means init (sklearn, host)
+def kmeans_case(seed=1000, n=2048, e=32, centres=300):
+    """A first-training-batch-sized set of latents with cluster structure (so k-means has something to find)."""
+    r = rs(seed)
+    c = f32(r.standard_normal((centres, e)))
+    return f32(c[r.randint(0, centres, size=n)] + 0.15 * r.standard_normal((n, e)))

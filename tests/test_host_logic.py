@@ -312,3 +312,24 @@ def test_native_index_json_text_equals_json_dump():
     buf = ctypes.create_string_buffer(cap)
     got = lib.lcrec_index_json_format(a.ctypes.data, 10, 4, 0, ctypes.addressof(buf), cap)
     assert buf.raw[:got] == want
+
+
+# ------------------------------------------------------------------ k-means init (host path)
+def test_kmeans_host_path_reproduces_reference_fixture():
+    """F10: lcrec_amd.layers.kmeans (sklearn on the host, the reference's own call, layers.py:69-82) under
+    np.random.seed(2024) gives the centres the imported reference gave -- for the scikit-learn version the fixture
+    was generated with (the reference pins none; another version is 'parity unpinned' and skipped)."""
+    import sklearn
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["fixtures"]["f10_kmeans.npz"]
+    if sklearn.__version__ != meta["sklearn"]:
+        pytest.skip(f"fixture generated with scikit-learn {meta['sklearn']}, this is {sklearn.__version__}")
+    from lcrec_amd import layers
+    g = np.load(os.path.join(ROOT, "tests", "golden", "f10_kmeans.npz"))
+    x = torch.from_numpy(gi.kmeans_case())
+    assert layers.KMEANS_IMPL == "sklearn"
+    for K, iters in ((256, 10), (64, 100)):
+        np.random.seed(2024)
+        c = layers.kmeans(x, K, iters)
+        assert c.dtype == torch.float32 and tuple(c.shape) == (K, 32)
+        # sklearn's Lloyd reduces per-thread partial sums in arrival order: identical up to fp32 rounding across runs
+        np.testing.assert_allclose(c.numpy(), g[f"centres_{K}_{iters}"], rtol=1e-4, atol=1e-5)
