@@ -233,6 +233,62 @@ int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook, const fl
                      const float *sum, int K, int e, float decay, float alpha, float keep, float eps,
                      void *stream);
 
+/* ---- the element-wise / column-reduction half of a training step -------------------
+ * Device pointers throughout; batch-sized inputs (n <= 2^20 rows); deterministic (no atomics): a column is summed by
+ * 8 row groups (rows r = g, g+8, ... in order) whose partials are added in group order.  Floating-point results are
+ * within 1e-5 of the torch ops they replace (the reference's own order is unspecified); pinned by the reference's
+ * F4 three-step trajectory. */
+
+/* Training-mode BatchNorm1d (+ ReLU) on the output t [n][features] of a Linear: index/models/layers.py:25-30
+ * (nn.BatchNorm1d at :26 in train(), activation at :28-30).  Batch mean and biased variance (two passes), y =
+ * [relu]((t - mean) * rstd * gamma + beta), rstd = 1/sqrt(var + eps); running_mean / running_var (may be NULL) are
+ * updated in place with `momentum`, running_var from the unbiased variance; mean_out / rstd_out [features] are what
+ * the backward needs.  n >= 2. */
+int lcrec_bn_relu_forward(const float *t, int64_t n, int features, const float *gamma, const float *beta, float eps,
+                          float momentum, float *running_mean, float *running_var, float *y, float *mean_out,
+                          float *rstd_out, int relu, void *stream);
+
+/* Backward of the above for gy = dL/dy (what autograd derives for layers.py:25-30 under loss.backward(),
+ * index/trainer.py:117):  g = gy * [y > 0];  dbeta = sum g;  dgamma = sum g*xhat;
+ * dt = gamma*rstd*(g - dbeta/n - xhat*dgamma/n);  dbias = sum dt -- the gradient of the Linear bias feeding the
+ * BatchNorm (zero up to rounding, as in the reference).  dgamma/dbeta/dbias may be NULL; dt may alias gy. */
+int lcrec_bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
+                           const float *mean, const float *rstd, int relu, float *dt_out, float *dgamma_out,
+                           float *dbeta_out, float *dbias_out, void *stream);
+
+/* ReLU mask and bias gradient of a Linear without BatchNorm (layers.py:23,28-30): g = gy * [y > 0] (relu != 0;
+ * g_out may alias gy or be NULL), dbias = column sums of g. */
+int lcrec_relu_bias_backward(const float *gy, const float *y, int64_t n, int features, int relu, float *g_out,
+                             float *dbias_out, void *stream);
+
+/* Scratch (bytes) of the two whole-tensor reductions below. */
+size_t lcrec_train_reduce_workspace(void);
+
+/* Reconstruction loss and its gradient, index/models/rqvae.py:74-85: l1 == 0: loss = mean (out-x)^2,
+ * grad = 2 (out-x)/count; l1 != 0: loss = mean |out-x|, grad = sign(out-x)/count.  count = n * in_dim elements;
+ * loss_out is a device float (fp64 accumulation); grad_out [count] or NULL. */
+int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *grad_out, float *loss_out,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (index/trainer.py:118) on a flat gradient buffer:
+ * norm_out[0] = ||grads||_2 (fp64 accumulation), norm_out[1] = min(1, max_norm / (norm + 1e-6)), the coefficient
+ * lcrec_adamw_step applies. */
+int lcrec_grad_norm_clip(const float *grads, int64_t count, float max_norm, float *norm_out, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* One optimiser step on flat fp32 buffers: torch.optim.AdamW (decoupled != 0) or Adam (index/trainer.py:49-81,119),
+ * preceded by the clipping of index/trainer.py:118 (grads *= clip[1], stored back; clip may be NULL) and with the
+ * learning rate of index/trainer.py:83-92,120 evaluated on the device from the step counter:
+ *   schedule -1: lr = base_lr;  0: constant after a linear warm-up;  1: linear warm-up, then linear decay to 0 at
+ *   total_steps (transformers' get_{constant,linear}_schedule_with_warmup multipliers, in double).
+ * *step (device int64) = optimiser steps taken so far; the call uses lr(*step) and bias corrections for step *step+1,
+ * then increments it -- so a captured hipGraph of a training step replays without any host-side scalar.
+ * lr_out: device float receiving the learning rate used, or NULL. */
+int lcrec_adamw_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, const float *clip,
+                     int64_t *step, double base_lr, double beta1, double beta2, double eps, double weight_decay,
+                     int decoupled, int schedule, int64_t warmup_steps, int64_t total_steps, float *lr_out,
+                     void *stream);
+
 /* Which items share an identical index tuple.  Replaces the Python string-set / dict passes of
  * index/trainer.py:139-150 (collision rate) and index/generate_indices.py:18-42
  * (check_collision, get_indices_count, get_collision_item), keeping get_collision_item's order:

@@ -55,6 +55,17 @@ _SIGNATURES = {
                                         _vp, _vp, _vp]),
     "lcrec_ema_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+    "lcrec_bn_relu_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp,
+                                             _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    "lcrec_bn_relu_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _vp,
+                                              _vp, _vp, _vp, _vp]),
+    "lcrec_relu_bias_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    "lcrec_train_reduce_workspace": (ctypes.c_size_t, []),
+    "lcrec_recon_loss_grad": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_grad_norm_clip": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_adamw_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_double, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int64, ctypes.c_int64, _vp, _vp]),
     "lcrec_collision_groups_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "lcrec_collision_groups": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _vp,
                                               _vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -26,7 +26,8 @@ const char *const kKernelNames[K_COUNT] = {"linear_fwd_128x128", "linear_fwd_128
                                            "rq_assign", "rq_sse_finalize", "vq_distance", "sinkhorn",
                                            "sinkhorn_small", "rq_apply_level", "code_stats", "ema_update",
                                            "collision_groups", "linear_fwd_pp_256x128", "linear_fwd_64x64", "sinkhorn_slab",
-                                           "sinkhorn_tiny"};
+                                           "sinkhorn_tiny", "bn_relu_forward", "bn_relu_backward", "relu_bias_backward",
+                                           "recon_loss_grad", "grad_norm_clip", "adamw_step"};
 
 struct TraceRec { int kernel; hipEvent_t start, stop; };
 static std::mutex g_trace_mu;
@@ -364,4 +365,49 @@ LCREC_API int lcrec_collision_groups(const int64_t *idx, int64_t n, int L, const
 {
     return collision_groups(idx, n, L, K, members_out, group_offsets_out, counters_out, workspace, workspace_bytes,
                             (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_bn_relu_forward(const float *t, int64_t n, int features, const float *gamma, const float *beta, float eps,
+                                    float momentum, float *running_mean, float *running_var, float *y, float *mean_out,
+                                    float *rstd_out, int relu, void *stream)
+{
+    return bn_relu_forward(t, n, features, gamma, beta, eps, momentum, running_mean, running_var, y, mean_out, rstd_out, relu,
+                           (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
+                                     const float *mean, const float *rstd, int relu, float *dt_out, float *dgamma_out,
+                                     float *dbeta_out, float *dbias_out, void *stream)
+{
+    return bn_relu_backward(gy, t, y, n, features, gamma, mean, rstd, relu, dt_out, dgamma_out, dbeta_out, dbias_out,
+                            (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_relu_bias_backward(const float *gy, const float *y, int64_t n, int features, int relu, float *g_out,
+                                       float *dbias_out, void *stream)
+{
+    return relu_bias_backward(gy, y, n, features, relu, g_out, dbias_out, (hipStream_t)stream);
+}
+
+LCREC_API size_t lcrec_train_reduce_workspace(void) { return train_reduce_workspace(); }
+
+LCREC_API int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *grad_out, float *loss_out,
+                                    void *workspace, size_t workspace_bytes, void *stream)
+{
+    return recon_loss_grad(out, x, count, l1, grad_out, loss_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_grad_norm_clip(const float *grads, int64_t count, float max_norm, float *norm_out, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    return grad_norm_clip(grads, count, max_norm, norm_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_adamw_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, const float *clip,
+                               int64_t *step, double base_lr, double beta1, double beta2, double eps, double weight_decay,
+                               int decoupled, int schedule, int64_t warmup_steps, int64_t total_steps, float *lr_out,
+                               void *stream)
+{
+    return adamw_step(params, grads, exp_avg, exp_avg_sq, count, clip, step, base_lr, beta1, beta2, eps, weight_decay, decoupled,
+                      schedule, warmup_steps, total_steps, lr_out, (hipStream_t)stream);
 }

@@ -30,7 +30,8 @@ inline int check_launch(const char *what)
 // Kernel ids for lcrec_trace_*.
 enum KernelId { K_LINEAR_128x128 = 0, K_LINEAR_128x64, K_LINEAR_128x32, K_RQ_ASSIGN, K_RQ_SSE_FINALIZE,
                 K_VQ_DISTANCE, K_SINKHORN, K_SINKHORN_SMALL, K_APPLY_LEVEL, K_CODE_STATS, K_EMA_UPDATE, K_COLLISION,
-                K_LINEAR_PP, K_LINEAR_64x64, K_SINKHORN_SLAB, K_SINKHORN_TINY, K_COUNT };
+                K_LINEAR_PP, K_LINEAR_64x64, K_SINKHORN_SLAB, K_SINKHORN_TINY, K_BN_FWD, K_BN_BWD, K_RELU_BIAS_BWD, K_LOSS,
+                K_GRAD_NORM, K_ADAMW, K_COUNT };
 extern const char *const kKernelNames[K_COUNT];
 bool trace_on();
 void trace_begin(int kernel, hipStream_t stream);
@@ -129,6 +130,22 @@ int collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t
                      int64_t *counters_out, void *workspace, size_t workspace_bytes, hipStream_t stream);
 int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,
                float decay, float alpha, float keep, float eps, hipStream_t stream);
+
+// training-step element-wise / reduction kernels (train_ops.hip)
+int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const float *beta, float eps, float momentum,
+                    float *running_mean, float *running_var, float *y, float *mean_out, float *rstd_out, int relu,
+                    hipStream_t stream);
+int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
+                     const float *rstd, int relu, float *dt, float *dgamma, float *dbeta, float *dbias, hipStream_t stream);
+int relu_bias_backward(const float *gy, const float *y, int64_t n, int F, int relu, float *g_out, float *dbias, hipStream_t stream);
+size_t train_reduce_workspace();
+int recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *g, float *loss, void *workspace,
+                    size_t workspace_bytes, hipStream_t stream);
+int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_out, void *workspace, size_t workspace_bytes,
+                   hipStream_t stream);
+int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const float *clip, int64_t *step, double base_lr,
+               double beta1, double beta2, double eps, double weight_decay, int decoupled, int schedule, int64_t warmup_steps,
+               int64_t total_steps, float *lr_out, hipStream_t stream);
 
 // host-side text (index_json.hip)
 int64_t index_json_bound(int64_t n, int L);

@@ -1080,6 +1080,12 @@ static int launch_sk_small_e(int e, const float *r, const float *cb, int K, cons
     return launch_sk_small<64, GLOBALQ>(r, cb, K, triples_dev, G, maxg, eps, iters, idx_out, idx_stride, qslab, stream);
 }
 
+struct SmallTable { static constexpr size_t CAP = 12; int64_t v[CAP]; };
+__global__ void write_table_kernel(int64_t *dst, SmallTable t, int count)
+{
+    if ((int)threadIdx.x < count) dst[threadIdx.x] = t.v[threadIdx.x];
+}
+
 int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
                     int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
                     lcrec_context *ctx, hipStream_t stream)
@@ -1128,7 +1134,15 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
         // table is a host temporary and the copy has to be waited for.
         const size_t tbytes = sizeof(int64_t) * triples.size();
         hipError_t he;
-        if (ctx) {
+        if (triples.size() <= SmallTable::CAP) {
+            // a handful of groups (a small training batch is ONE): the table travels as a kernel argument -- no host
+            // buffer whose lifetime matters, no wait, and safe to capture in a hipGraph (a captured copy would re-read a
+            // host address on every replay)
+            SmallTable tb;
+            for (size_t i = 0; i < triples.size(); ++i) tb.v[i] = triples[i];
+            hipLaunchKernelGGL(write_table_kernel, dim3(1), dim3(64), 0, stream, triples_dev, tb, (int)triples.size());
+            he = hipGetLastError();
+        } else if (ctx) {
             int slot = -1;
             void *pin = ctx->ring_acquire(tbytes, &slot);
             if (!pin) return LCREC_EHIP;

@@ -1,0 +1,268 @@
+"""The training step of the reference's index/trainer.py:111-123 as ONE hipGraph.
+
+`Trainer._train_epoch` in the reference is, per batch: zero_grad -> model(data) -> compute_loss -> isnan check ->
+backward -> clip_grad_norm_(1.0) -> optimizer.step -> scheduler.step -> two loss.item().  Driven
+from Python through autograd that is ~170 kernel launches and ~2 ms of host work per step; at the reference's batch
+size (1024, index/run.sh:2) the GPU needs less than that, so the step is host-bound.
+
+This module runs the same arithmetic as a straight line of library calls -- no autograd graph, every product through
+the same lcrec_* entry points the module API uses, so forward values and GEMM gradients are bit-identical to it:
+
+    encoder  [Linear -> (BatchNorm batch statistics) -> ReLU] x 7      lcrec_linear_forward, lcrec_bn_relu_forward
+    quantiser                                                          quantize.quantize_values (rq_assign / sinkhorn / code_stats)
+    decoder  same
+    loss     mse|l1 + quant_loss_weight * rq_loss, and d loss / d out   lcrec_recon_loss_grad
+    backward decoder, closed-form quantiser gradients, encoder         lcrec_bn_relu_backward / lcrec_relu_bias_backward,
+                                                                       lcrec_linear_backward (dW written straight into the
+                                                                       flat gradient buffer)
+    clip 1.0 + AdamW + warm-up schedule                                lcrec_grad_norm_clip, lcrec_adamw_step (learning
+                                                                       rate and bias corrections from a device step counter)
+    loss sums, NaN flag                                                device accumulators, read once per epoch
+
+and captures it with torch.cuda.CUDAGraph (a hipGraph) once per batch size: a step is then one index_select, one copy
+and one graph launch on the host.  Parameters, gradients and both Adam moments live in four flat fp32 buffers; the
+module's nn.Parameters (and the torch optimizer's state entries, so checkpoints keep the reference's layout) are views
+into them.
+
+What the engine does not cover falls back to the autograd path in trainer.py, unchanged: data-parallel runs, the EMA
+codebook update of index_improve/, dropout > 0, activations other than ReLU, optimisers other than Adam/AdamW,
+--strict_nan_check (the reference's per-step host sync).
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .quantize import level_plan, quantize_values
+
+_ALIGN = 64     # floats: every parameter starts on a 256-byte boundary of the flat buffers
+
+
+class TrainEngine:
+    def __init__(self, model, optimizer, schedule, warmup_steps, total_steps, max_norm=1.0, use_graph=True):
+        """schedule: "linear" | "constant" (index/trainer.py:83-92) or None (fixed learning rate)."""
+        self.model = model
+        self.optimizer = optimizer
+        self.max_norm = float(max_norm)
+        self.use_graph = use_graph
+        self.schedule = {"linear": 1, "constant": 0, None: -1}[schedule]
+        self.warmup_steps, self.total_steps = int(warmup_steps), int(total_steps)
+        group = optimizer.param_groups[0]
+        self.base_lr = float(group.get("initial_lr", group["lr"]))
+        self.betas = tuple(group["betas"])
+        self.eps = float(group["eps"])
+        self.weight_decay = float(group["weight_decay"])
+        self.decoupled = isinstance(optimizer, torch.optim.AdamW)
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.device = self.params[0].device
+        self._prior_steps = 0
+        self._flatten()
+        dev = self.device
+        self.step_count = torch.full((), self._prior_steps, dtype=torch.int64, device=dev)   # optimiser steps taken (device side)
+        self.host_steps = self._prior_steps
+        self.clip = torch.zeros(2, dtype=torch.float32, device=dev)          # (grad norm, clip coefficient) of the last step
+        self.lr_used = torch.zeros((), dtype=torch.float32, device=dev)
+        self.loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.recon_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.last = torch.zeros(3, dtype=torch.float32, device=dev)          # loss, recon, rq_loss of the last step
+        self.bad = torch.zeros(2, dtype=torch.bool, device=dev)              # [loss was NaN, Sinkhorn solver gave up]
+        self._graphs = {}                                                    # batch rows -> (graph, static input)
+        self._seen = {}                                                      # batch rows -> eager steps done at that size
+        self.graph_replays = 0
+
+    # ------------------------------------------------------------------ support matrix
+    @staticmethod
+    def unsupported_reason(model, optimizer, args=None, dist=None, use_ema=False):
+        if dist is not None:
+            return "data-parallel run"
+        if use_ema:
+            return "EMA codebook update (index_improve)"
+        if not isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
+            return f"optimizer {type(optimizer).__name__}"
+        if len(optimizer.param_groups) != 1 or optimizer.param_groups[0].get("amsgrad") or optimizer.param_groups[0].get("maximize"):
+            return "optimizer options"
+        if args is not None and getattr(args, "strict_nan_check", False):
+            return "--strict_nan_check"
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            return "model is not on a HIP device"
+        if model.loss_type not in ("mse", "l1"):
+            return f"loss_type {model.loss_type}"
+        if model.e_dim not in (16, 32, 64):
+            return f"e_dim {model.e_dim}"
+        for mlp in (model.encoder, model.decoder):
+            if mlp.dropout > 0:
+                return "dropout"
+            if not mlp.fusable():
+                return "non-ReLU activation"
+            for g in mlp._groups:
+                lin = mlp.mlp_layers[g["linear"]]
+                if lin.bias is None or lin.in_features % 4 or lin.out_features % 4:
+                    return "Linear shape"
+                if "bn" in g:
+                    bn = mlp.mlp_layers[g["bn"]]
+                    if type(bn) is not nn.BatchNorm1d or bn.momentum is None or not bn.track_running_stats or not bn.affine:
+                        return "BatchNorm options"
+        return None
+
+    # ------------------------------------------------------------------ flat buffers
+    def _flatten(self):
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        dev = self.device
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._step_f32 = torch.zeros((), dtype=torch.float32, device=dev)
+        self.grad_view = {}
+        with torch.no_grad():
+            for p, off in zip(self.params, offs):
+                n = p.numel()
+                view = lambda flat: flat[off:off + n].view(p.shape)
+                view(self.flat_p).copy_(p.data)
+                p.data = view(self.flat_p)
+                p.grad = view(self.flat_g)
+                self.grad_view[p] = p.grad
+                state = self.optimizer.state[p]
+                if "exp_avg" in state:                                   # steps were taken before the engine took over
+                    view(self.flat_m).copy_(state["exp_avg"])
+                    view(self.flat_v).copy_(state["exp_avg_sq"])
+                    self._prior_steps = int(float(state["step"]))
+                state["step"] = self._step_f32
+                state["exp_avg"] = view(self.flat_m)
+                state["exp_avg_sq"] = view(self.flat_v)
+
+    # ------------------------------------------------------------------ the step, as library calls
+    def _mlp_forward(self, mlp, h):
+        saved = []
+        mods = mlp.mlp_layers
+        for g in mlp._groups:
+            lin = mods[g["linear"]]
+            relu = "act" in g
+            if "bn" in g:
+                bn = mods[g["bn"]]
+                t = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=False)
+                y, mean, rstd = ops.bn_relu_forward(t, bn.weight.data, bn.bias.data, bn.eps, bn.momentum, bn.running_mean,
+                                                    bn.running_var, relu=relu)
+                bn.num_batches_tracked.add_(1)
+                saved.append((h, lin, bn, relu, t, y, mean, rstd))
+            else:
+                y = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=relu)
+                saved.append((h, lin, None, relu, None, y, None, None))
+            h = y
+        return h, saved
+
+    def _mlp_backward(self, saved, g, need_input_grad):
+        gv = self.grad_view
+        for i in range(len(saved) - 1, -1, -1):
+            h, lin, bn, relu, t, y, mean, rstd = saved[i]
+            if bn is not None:
+                dt, _, _, _ = ops.bn_relu_backward(g, t, y, bn.weight.data, mean, rstd, relu, dgamma_out=gv[bn.weight],
+                                                   dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias])
+            else:
+                dt, _ = ops.relu_bias_backward(g, y, relu, dbias_out=gv[lin.bias], inplace=True)
+            need_gx = i > 0 or need_input_grad
+            w = lin.weight.data
+            out_dim = w.shape[0]
+            pad = (-out_dim) % 32                       # layers._LinearAct.backward: K slice of the k-major kernels
+            if pad:
+                dt = torch.nn.functional.pad(dt, (0, pad))
+                w = torch.nn.functional.pad(w, (0, 0, 0, pad))
+                gx, gw = ops.linear_backward(dt, h, w, need_gx, True)
+                gv[lin.weight].copy_(gw[:out_dim])
+            else:
+                gx, _ = ops.linear_backward(dt, h, w, need_gx, True, gw_out=gv[lin.weight])
+            g = gx
+        return g
+
+    def _run(self, x, eager):
+        m = self.model
+        levels = list(m.rq.vq_layers)
+        z, enc = self._mlp_forward(m.encoder, x)
+        if eager and any(not q.initted for q in levels):
+            m.rq._lazy_kmeans(z.reshape(-1, m.e_dim), True)                 # vq.py:67-68, first training batch only
+        cbs = [q.embedding.weight.data for q in levels]
+        q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), True, True)
+        out, dec = self._mlp_forward(m.decoder, q["xq"])
+        recon, g_out = ops.recon_loss_grad(out, x, m.loss_type)
+        rq_loss = q["rq_loss"]
+        loss = recon + m.quant_loss_weight * rq_loss                         # rqvae.py:83
+        g_xq = self._mlp_backward(dec, g_out, True)
+        g_loss = torch.full((), float(m.quant_loss_weight), dtype=torch.float32, device=x.device)
+        gz = q["commit"] * g_loss
+        gz = gz + g_xq                                                       # quantize._Quantize.backward, same order
+        for lvl, cg in zip(levels, q["code_grads"]):
+            torch.mul(cg, g_loss, out=self.grad_view[lvl.embedding.weight])
+        self._mlp_backward(enc, gz, False)
+        ops.grad_norm_clip(self.flat_g, self.max_norm, out=self.clip)
+        ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.base_lr, self.betas, self.eps,
+                       self.weight_decay, self.decoupled, clip=self.clip, schedule=self.schedule,
+                       warmup_steps=self.warmup_steps, total_steps=self.total_steps, lr_out=self.lr_used)
+        self.loss_sum.add_(loss.double())
+        self.recon_sum.add_(recon.double())
+        self.last.copy_(torch.stack([loss, recon, rq_loss]))
+        self.bad[0].logical_or_(torch.isnan(loss))
+        for _msg, flag in ops.deferred_checks.drain():                       # Sinkhorn poison flags of this step
+            self.bad[1].logical_or_(flag)
+
+    # ------------------------------------------------------------------ driving it
+    def step(self, batch):
+        """One training step on `batch` ([rows, in_dim] on the engine's device)."""
+        rows = int(batch.shape[0])
+        self.host_steps += 1
+        entry = self._graphs.get(rows)
+        if entry is not None:
+            entry[1].copy_(batch)
+            entry[0].replay()
+            self.graph_replays += 1
+            return
+        done = self._seen.get(rows, 0)
+        lazy = any(not q.initted for q in self.model.rq.vq_layers)
+        if not self.use_graph or done < 1 or lazy:
+            # the first step at a batch size runs eagerly: it creates the stream's workspaces, runs the one-off k-means
+            # initialisation (host sklearn), and it is a real training step
+            with torch.no_grad(), ops.deferred_checks():
+                self._run(batch.contiguous(), eager=True)
+            self._seen[rows] = done + 1
+            return
+        static = batch.clone()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.no_grad(), ops.deferred_checks():
+            with torch.cuda.graph(graph, stream=side):
+                self._run(static, eager=False)
+        self._graphs[rows] = (graph, static)
+        graph.replay()                                                       # capture records, replay executes: this step
+        self.graph_replays += 1
+
+    def begin_epoch(self):
+        self.loss_sum.zero_()
+        self.recon_sum.zero_()
+
+    def end_epoch(self, scheduler=None):
+        """(sum of losses, sum of reconstruction losses) over the epoch's steps -- trainer.py:122-125 -- after checking
+        the device-side flags; brings the host-side scheduler and optimizer bookkeeping up to date."""
+        vals = torch.stack([self.loss_sum, self.recon_sum]).cpu()
+        bad = self.bad.cpu()
+        if bool(bad[1]):
+            raise ops._lib.LcrecError("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "
+                                      "set LCREC_SINKHORN_PERSISTENT=0 to use the multi-launch solver")
+        if bool(bad[0]):
+            raise ValueError("Training loss is nan")
+        self.sync_host_state(scheduler)
+        return float(vals[0]), float(vals[1])
+
+    def sync_host_state(self, scheduler=None):
+        """Make what the host can see agree with the device: the optimizer's per-parameter `step` entries (checkpoints)
+        and the LambdaLR scheduler's counters and `lr` (logging, get_last_lr)."""
+        self._step_f32.fill_(float(self.host_steps))
+        if scheduler is not None and scheduler.last_epoch != self.host_steps:
+            scheduler.last_epoch = self.host_steps
+            scheduler._step_count = self.host_steps + 1
+            lrs = [base * lmbda(self.host_steps) for base, lmbda in zip(scheduler.base_lrs, scheduler.lr_lambdas)]
+            for group, lr in zip(self.optimizer.param_groups, lrs):
+                group["lr"] = lr
+            scheduler._last_lr = lrs

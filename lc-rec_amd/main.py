@@ -67,6 +67,9 @@ def parse_args(argv=None):
     parser.add_argument("--strict_nan_check", action="store_true",
                         help="raise 'Training loss is nan' before the offending step's backward (a host sync per step, the "
                              "reference's timing) instead of one step later")
+    parser.add_argument("--train_engine", type=str, default="auto", choices=["auto", "off"],
+                        help="auto = run the training step as one captured hipGraph when the configuration allows it "
+                             "(lcrec_amd.engine); off = always the autograd path")
     parser.add_argument("--kmeans_impl", type=str, default="sklearn", choices=["sklearn", "device"],
                         help="sklearn = the reference's host KMeans call; device = k-means++/Lloyd in HBM")
     args = parser.parse_args(argv)

@@ -162,10 +162,12 @@ def linear_forward(x, weight, bias=None, bn_scale=None, bn_shift=None, relu=Fals
     return y
 
 
-def linear_backward(gy, x, weight, need_gx=True, need_gw=True):
+def linear_backward(gy, x, weight, need_gx=True, need_gw=True, gw_out=None):
     """(gx, gw) of y = x W^T for a given gy = dL/dy (autograd's LinearBackward; include/lcrec.h,
     lcrec_linear_backward): gx = gy W, gw = gy^T x, every operand read as stored.  Raises
-    LcrecError(LCREC_EUNSUPPORTED) for shapes the k-major kernels do not cover."""
+    LcrecError(LCREC_EUNSUPPORTED) for shapes the k-major kernels do not cover.
+    gw_out: optional contiguous [out_dim, in_dim] tensor the weight gradient is written into (a view of a flat
+    gradient buffer)."""
     lib = _lib.load()
     gy, x, weight = _dev(gy, "gy"), _dev(x, "x"), _dev(weight, "weight")
     n, out_dim = gy.shape
@@ -173,7 +175,11 @@ def linear_backward(gy, x, weight, need_gx=True, need_gw=True):
     if x.shape[0] != n or tuple(weight.shape) != (out_dim, in_dim):
         raise _lib.LcrecError(f"linear_backward: shapes gy {tuple(gy.shape)}, x {tuple(x.shape)}, W {tuple(weight.shape)}")
     gx = torch.empty((n, in_dim), dtype=torch.float32, device=gy.device) if need_gx else None
-    gw = torch.empty((out_dim, in_dim), dtype=torch.float32, device=gy.device) if need_gw else None
+    gw = None
+    if need_gw:
+        gw = gw_out if gw_out is not None else torch.empty((out_dim, in_dim), dtype=torch.float32, device=gy.device)
+        if tuple(gw.shape) != (out_dim, in_dim) or not gw.is_contiguous() or gw.dtype != torch.float32:
+            raise _lib.LcrecError("gw_out must be a contiguous float32 [out_dim, in_dim] tensor")
     with _on(gy.device):
         nbytes = lib.lcrec_linear_backward_workspace(n, in_dim, out_dim) if need_gw else 0
         ws = _workspace(nbytes, gy.device)
@@ -348,6 +354,14 @@ class deferred_checks:
         if _deferred is not None and len(_deferred) >= self.every:
             self.flush()
 
+    @staticmethod
+    def drain():
+        """Hand the collected (message, device bool) pairs to the caller without evaluating them (a graph capture folds
+        them into a device-side flag instead of reading them back)."""
+        global _deferred
+        pending, _deferred = (_deferred or []), []
+        return pending
+
     def __exit__(self, exc_type, exc, tb):
         global _deferred
         try:
@@ -469,6 +483,118 @@ def index_json_text(idx_rows, first_item=0):
     if got < 0:
         _lib.check(int(got), "lcrec_index_json_format")
     return buf[:got].tobytes()
+
+
+# ---- training-step kernels (csrc/train_ops.hip)
+def _vec(t, name, F):
+    if t is None:
+        return None
+    t = _dev(t, name)
+    if t.numel() != F:
+        raise _lib.LcrecError(f"{name} must have {F} elements")
+    return t
+
+
+def bn_relu_forward(t, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, relu=True):
+    """Training-mode BatchNorm1d (+ReLU) of a Linear's output (layers.py:25-30): returns (y, mean, rstd); the running
+    statistics (contiguous fp32 buffers of the module) are updated in place."""
+    lib = _lib.load()
+    t = _dev(t, "t")
+    n, F = t.shape
+    gamma, beta = _vec(gamma, "gamma", F), _vec(beta, "beta", F)
+    for name, buf in (("running_mean", running_mean), ("running_var", running_var)):
+        if buf is not None and not (buf.is_cuda and buf.is_contiguous() and buf.dtype == torch.float32 and buf.numel() == F):
+            raise _lib.LcrecError(f"{name} must be a contiguous float32 device buffer of {F} elements")
+    y = torch.empty_like(t)
+    mean = torch.empty(F, dtype=torch.float32, device=t.device)
+    rstd = torch.empty(F, dtype=torch.float32, device=t.device)
+    with _on(t.device):
+        rc = lib.lcrec_bn_relu_forward(_ptr(t), n, F, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(running_mean),
+                                       _ptr(running_var), _ptr(y), _ptr(mean), _ptr(rstd), int(bool(relu)), _stream_ptr())
+    _lib.check(rc, "lcrec_bn_relu_forward")
+    return y, mean, rstd
+
+
+def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, dbeta_out=None, dbias_out=None):
+    """(dt, dgamma, dbeta, dbias) of y = [relu](bn(t)) for gy = dL/dy (see lcrec_bn_relu_backward); the three vector
+    outputs may be given (views of a flat gradient buffer)."""
+    lib = _lib.load()
+    gy, t = _dev(gy, "gy"), _dev(t, "t")
+    y = None if y is None else _dev(y, "y")
+    n, F = t.shape
+    gamma = _vec(gamma, "gamma", F)
+    mk = lambda o: o if o is not None else torch.empty(F, dtype=torch.float32, device=t.device)
+    dgamma, dbeta, dbias = mk(dgamma_out), mk(dbeta_out), mk(dbias_out)
+    dt = torch.empty_like(t)
+    with _on(t.device):
+        rc = lib.lcrec_bn_relu_backward(_ptr(gy), _ptr(t), _ptr(y), n, F, _ptr(gamma), _ptr(_vec(mean, "mean", F)),
+                                        _ptr(_vec(rstd, "rstd", F)), int(bool(relu)), _ptr(dt), _ptr(dgamma), _ptr(dbeta),
+                                        _ptr(dbias), _stream_ptr())
+    _lib.check(rc, "lcrec_bn_relu_backward")
+    return dt, dgamma, dbeta, dbias
+
+
+def relu_bias_backward(gy, y, relu=True, dbias_out=None, inplace=False):
+    """(g, dbias): g = gy * [y > 0] (or gy itself when relu is False), dbias = column sums of g."""
+    lib = _lib.load()
+    gy = _dev(gy, "gy")
+    n, F = gy.shape
+    y = _dev(y, "y") if relu else None
+    g = gy if (inplace or not relu) else torch.empty_like(gy)
+    dbias = dbias_out if dbias_out is not None else torch.empty(F, dtype=torch.float32, device=gy.device)
+    with _on(gy.device):
+        rc = lib.lcrec_relu_bias_backward(_ptr(gy), _ptr(y), n, F, int(bool(relu)), _ptr(g) if relu else None, _ptr(dbias),
+                                          _stream_ptr())
+    _lib.check(rc, "lcrec_relu_bias_backward")
+    return g, dbias
+
+
+def recon_loss_grad(out, x, loss_type="mse", want_grad=True):
+    """(loss float32 scalar tensor, grad | None) of rqvae.py:74-85's reconstruction term."""
+    lib = _lib.load()
+    out, x = _dev(out, "out"), _dev(x, "x")
+    if out.shape != x.shape:
+        raise _lib.LcrecError(f"recon_loss_grad: shapes {tuple(out.shape)} vs {tuple(x.shape)}")
+    if loss_type not in ("mse", "l1"):
+        raise ValueError("incompatible loss type")
+    g = torch.empty_like(out) if want_grad else None
+    loss = torch.empty((), dtype=torch.float32, device=out.device)
+    with _on(out.device):
+        ws = _workspace(lib.lcrec_train_reduce_workspace(), out.device)
+        rc = lib.lcrec_recon_loss_grad(_ptr(out), _ptr(x), out.numel(), int(loss_type == "l1"), _ptr(g), _ptr(loss), _ptr(ws),
+                                       ws.numel(), _stream_ptr())
+    _lib.check(rc, "lcrec_recon_loss_grad")
+    return loss, g
+
+
+def grad_norm_clip(flat_grads, max_norm=1.0, out=None):
+    """float32 [2] device tensor: (global L2 norm, clip coefficient) of a flat gradient buffer (trainer.py:118)."""
+    lib = _lib.load()
+    g = _dev(flat_grads, "grads")
+    res = out if out is not None else torch.empty(2, dtype=torch.float32, device=g.device)
+    with _on(g.device):
+        ws = _workspace(lib.lcrec_train_reduce_workspace(), g.device)
+        rc = lib.lcrec_grad_norm_clip(_ptr(g), g.numel(), float(max_norm), _ptr(res), _ptr(ws), ws.numel(), _stream_ptr())
+    _lib.check(rc, "lcrec_grad_norm_clip")
+    return res
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=True,
+               clip=None, schedule=-1, warmup_steps=0, total_steps=0, lr_out=None):
+    """One AdamW/Adam step on flat fp32 buffers, all updated in place (see lcrec_adamw_step); `step` is a device int64
+    scalar the call increments."""
+    lib = _lib.load()
+    for name, t in (("params", params), ("grads", grads), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == params.numel()):
+            raise _lib.LcrecError(f"{name} must be a contiguous float32 device buffer of {params.numel()} elements")
+    if not (step.is_cuda and step.dtype == torch.int64 and step.numel() == 1):
+        raise _lib.LcrecError("step must be a device int64 scalar")
+    with _on(params.device):
+        rc = lib.lcrec_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), _ptr(clip),
+                                  _ptr(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                  int(bool(decoupled)), int(schedule), int(warmup_steps), int(total_steps), _ptr(lr_out),
+                                  _stream_ptr())
+    _lib.check(rc, "lcrec_adamw_step")
 
 
 def trace_enable(on=True):

@@ -16,63 +16,73 @@ from . import dist as ldist
 from . import ops
 
 
+def quantize_values(zc, cbs, beta, plan, want_stats, training):
+    """Values of the L-level quantiser on detached, contiguous inputs -- shared by the autograd node below and by the
+    graph-captured training step (engine.py), which calls it without autograd.
+    Returns dict(xq, rq_loss, idx, stats, resid_in, code_grads, commit); the last two (closed-form gradient factors, see
+    the module docstring) only with want_stats."""
+    n, e = zc.shape
+    L = len(cbs)
+    dev = zc.device
+    idx = torch.empty((n, L), dtype=torch.int64, device=dev)
+    sse = torch.zeros(L, dtype=torch.float64, device=dev)
+    resid_in = [None] * L
+    r, xq, l = zc, None, 0
+    while l < L:
+        if plan[l] is not None:
+            eps, iters = plan[l]
+            world = ldist.current()
+            if world.enabled and training:
+                # data parallel: the Sinkhorn problem is the GLOBAL batch (dist.py)
+                r_all, (lo, hi) = world.gather_rows_with_slice(r)
+                idx[:, l] = ops.sinkhorn_assign(r_all, cbs[l], eps, iters)[lo:hi]
+            else:
+                ops.sinkhorn_assign(r, cbs[l], eps, iters, out=idx[:, l])
+            resid_in[l] = r
+            xq, r, s = ops.rq_apply_level(r, cbs[l], idx[:, l], xq=xq, want_sse=True)
+            sse[l] = s[0]
+            l += 1
+            continue
+        m = l
+        while m < L and plan[m] is None:
+            m += 1
+        flat, ks = ops.flatten_codebooks(cbs[l:m])
+        ridx, xq, rsse, resid = ops.rq_assign(r, flat, ks, want_xq=True, want_sse=True, want_resid=True, xq_init=xq)
+        idx[:, l:m] = ridx
+        sse[l:m] = rsse
+        for t in range(l, m):
+            resid_in[t] = resid[t - l]
+        r = resid[m - l]
+        l = m
+    # vq.py:90-92: loss_l = mse + beta*mse (fp32), rq.py:53: mean over levels
+    mse = (sse / float(n * e)).to(torch.float32)
+    level_loss = mse + beta * mse
+    out = {"xq": xq, "rq_loss": level_loss.mean(), "idx": idx, "stats": None, "resid_in": resid_in,
+           "code_grads": None, "commit": None}
+    if want_stats:
+        stats = [ops.code_stats(idx[:, t], resid_in[t], cbs[t].shape[0]) for t in range(L)]
+        scale = 2.0 / (L * n * e)
+        out["stats"] = stats
+        out["code_grads"] = [scale * (cnt.unsqueeze(1) * cbs[t] - tot) for t, (cnt, tot) in enumerate(stats)]
+        out["commit"] = (beta * scale) * (zc - cbs[0].index_select(0, idx[:, 0]))
+    return out
+
+
 class _Quantize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, beta, plan, want_stats, side, *codebooks):
         """plan[l] = (epsilon, iters) for a Sinkhorn level, None for an argmin level.
         side: dict that receives the per-level statistics and level inputs (EMA needs them)."""
-        n, e = z.shape
-        L = len(codebooks)
-        dev = z.device
         zc = z.detach().contiguous()
         cbs = [c.detach().contiguous() for c in codebooks]
-        idx = torch.empty((n, L), dtype=torch.int64, device=dev)
-        sse = torch.zeros(L, dtype=torch.float64, device=dev)
-        resid_in = [None] * L
-        r, xq, l = zc, None, 0
-        while l < L:
-            if plan[l] is not None:
-                eps, iters = plan[l]
-                world = ldist.current()
-                if world.enabled and side.get("training"):
-                    # data parallel: the Sinkhorn problem is the GLOBAL batch (dist.py)
-                    r_all, (lo, hi) = world.gather_rows_with_slice(r)
-                    idx[:, l] = ops.sinkhorn_assign(r_all, cbs[l], eps, iters)[lo:hi]
-                else:
-                    ops.sinkhorn_assign(r, cbs[l], eps, iters, out=idx[:, l])
-                resid_in[l] = r
-                xq, r, s = ops.rq_apply_level(r, cbs[l], idx[:, l], xq=xq, want_sse=True)
-                sse[l] = s[0]
-                l += 1
-                continue
-            m = l
-            while m < L and plan[m] is None:
-                m += 1
-            flat, ks = ops.flatten_codebooks(cbs[l:m])
-            ridx, xq, rsse, resid = ops.rq_assign(r, flat, ks, want_xq=True, want_sse=True, want_resid=True,
-                                                  xq_init=xq)
-            idx[:, l:m] = ridx
-            sse[l:m] = rsse
-            for t in range(l, m):
-                resid_in[t] = resid[t - l]
-            r = resid[m - l]
-            l = m
-        # vq.py:90-92: loss_l = mse + beta*mse (fp32), rq.py:53: mean over levels
-        mse = (sse / float(n * e)).to(torch.float32)
-        level_loss = mse + beta * mse
-        rq_loss = level_loss.mean()
-
-        stats = None
-        if want_stats:
-            stats = [ops.code_stats(idx[:, t], resid_in[t], cbs[t].shape[0]) for t in range(L)]
-            scale = 2.0 / (L * n * e)
-            ctx.code_grads = [scale * (cnt.unsqueeze(1) * cbs[t] - tot) for t, (cnt, tot) in enumerate(stats)]
-            ctx.commit = (beta * scale) * (zc - cbs[0].index_select(0, idx[:, 0]))
+        v = quantize_values(zc, cbs, beta, plan, want_stats, bool(side.get("training")))
+        ctx.code_grads = v["code_grads"]
+        ctx.commit = v["commit"]
         ctx.has_grads = want_stats
-        ctx.mark_non_differentiable(idx)
-        side["stats"] = stats
-        side["resid_in"] = resid_in
-        return xq, rq_loss, idx
+        ctx.mark_non_differentiable(v["idx"])
+        side["stats"] = v["stats"]
+        side["resid_in"] = v["resid_in"]
+        return v["xq"], v["rq_loss"], v["idx"]
 
     @staticmethod
     def backward(ctx, g_xq, g_loss, _g_idx):
@@ -87,12 +97,17 @@ class _Quantize(torch.autograd.Function):
         return (gz, None, None, None, None, *gcs)
 
 
+def level_plan(layers, use_sk):
+    """plan[l] = (epsilon, iters) for a level assigned by Sinkhorn (vq.py:76-83), None for an argmin level (:75)."""
+    return [((q.sk_epsilon, q.sk_iters) if (use_sk and q.sk_epsilon > 0) else None) for q in layers]
+
+
 def quantize(z, layers, beta, use_sk, training):
     """Shared body of VectorQuantizer.forward / ResidualVectorQuantizer.forward on [n, e] latents.
 
     Returns (x_q, mean level loss, idx [n, L], side) where side["stats"] is the per-level (count, sum)
     list (None when neither training nor differentiating) and side["resid_in"] the level inputs."""
-    plan = [((q.sk_epsilon, q.sk_iters) if (use_sk and q.sk_epsilon > 0) else None) for q in layers]
+    plan = level_plan(layers, use_sk)
     cbs = [q.embedding.weight for q in layers]
     want = torch.is_grad_enabled() and (z.requires_grad or any(c.requires_grad for c in cbs))
     want_stats = want or training

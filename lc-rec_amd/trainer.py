@@ -102,6 +102,8 @@ class Trainer(object):
         self.scheduler = self._get_scheduler()
         self.model = self.model.to(self.device)
         self.dist = None            # set by lcrec_amd.dist.attach() for item-sharded data parallel
+        self.engine = None          # engine.TrainEngine once the first epoch has decided whether it applies
+        self._engine_decided = False
 
     # reference attribute names, for scripts that poke at them
     @property
@@ -171,8 +173,33 @@ class Trainer(object):
             if bool(self._nan_host):
                 raise ValueError("Training loss is nan")
 
+    def _get_engine(self):
+        """The graph-captured step (engine.py) when the configuration allows it; None -> the autograd path below."""
+        if not self._engine_decided:
+            self._engine_decided = True
+            from .engine import TrainEngine
+            reason = TrainEngine.unsupported_reason(self.model, self.optimizer, self.args, self.dist, self.use_ema)
+            if reason is None and (os.environ.get("LCREC_TRAIN_ENGINE", "1") == "0"
+                                   or getattr(self.args, "train_engine", "auto") == "off"):
+                reason = "switched off (--train_engine off / LCREC_TRAIN_ENGINE=0)"
+            if reason is None:
+                kind = "linear" if self.lr_scheduler_type.lower() == "linear" else "constant"
+                self.engine = TrainEngine(self.model, self.optimizer, kind, self.warmup_steps, self.max_steps)
+                self.logger.info("training step: one captured hipGraph per batch size (lcrec_amd.engine)")
+            else:
+                self.logger.info("training step: autograd path (%s)", reason)
+        return self.engine
+
     def _train_epoch(self, train_data, epoch_idx):
         self.model.train()
+        engine = self._get_engine()
+        if engine is not None:
+            iter_data = tqdm(train_data, total=len(train_data), ncols=100, desc=set_color(f"Train {epoch_idx}", "pink"),
+                             disable=not self._is_main())
+            engine.begin_epoch()
+            for data in iter_data:
+                engine.step(data.to(self.device))
+            return engine.end_epoch(self.scheduler)      # raises "Training loss is nan" / solver errors of the epoch
         total_loss = torch.zeros((), dtype=torch.float64, device=self.device)
         total_recon = torch.zeros((), dtype=torch.float64, device=self.device)
         iter_data = tqdm(train_data, total=len(train_data), ncols=100, desc=set_color(f"Train {epoch_idx}", "pink"),

@@ -1,0 +1,254 @@
+"""The training step's own kernels (csrc/train_ops.hip) and the graph-captured step (lcrec_amd/engine.py).
+
+Floating-point kernels: checked against plain torch fp32/fp64 ops on the CPU (the reference's ops: nn.BatchNorm1d in
+train(), F.mse_loss / F.l1_loss, clip_grad_norm_, torch.optim.AdamW -- index/models/layers.py:25-30,
+index/models/rqvae.py:74-85, index/trainer.py:118-120) within 1e-5, and the whole step against the reference's recorded
+three-step trajectory (tests/golden/f4_step_bn{0,1}.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def _rs(seed):
+    return np.random.RandomState(seed)
+
+
+@pytest.mark.parametrize("n,feat,relu", [(1024, 2048, True), (475, 96, True), (2, 32, True), (2048, 64, False), (333, 100, True)])
+def test_bn_relu_forward_backward_match_torch(hip, n, feat, relu):
+    rs = _rs(n + feat)
+    t = gi.f32(rs.standard_normal((n, feat)) * 2.0 + rs.standard_normal(feat) * 3.0)       # means far from 0
+    gamma, beta = gi.f32(1 + 0.2 * rs.standard_normal(feat)), gi.f32(0.3 * rs.standard_normal(feat))
+    rm, rv = gi.f32(0.1 * rs.standard_normal(feat)), gi.f32(0.5 + rs.uniform(size=feat))
+    gy = gi.f32(rs.standard_normal((n, feat)))
+    # reference: torch ops in fp64 on the CPU (what nn.BatchNorm1d + ReLU + autograd compute, without fp32 noise)
+    td = torch.from_numpy(t).double().requires_grad_(True)
+    gd, bd = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    rmd, rvd = torch.from_numpy(rm).double(), torch.from_numpy(rv).double()
+    yd = F.batch_norm(td, rmd, rvd, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    if relu:
+        yd = F.relu(yd)
+    yd.backward(torch.from_numpy(gy).double())
+    dev = torch.device(DEV)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    rm_d, rv_d = d(rm), d(rv)
+    y, mean, rstd = hip.ops.bn_relu_forward(d(t), d(gamma), d(beta), 1e-5, 0.1, rm_d, rv_d, relu=relu)
+    np.testing.assert_allclose(y.cpu().numpy(), yd.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rmd.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rvd.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mean.cpu().numpy(), t.astype(np.float64).mean(0), rtol=1e-6, atol=1e-6)
+    dt, dg, db, dbias = hip.ops.bn_relu_backward(d(gy), d(t), y, d(gamma), mean, rstd, relu=relu)
+    scale = float(np.abs(td.grad.numpy()).max())
+    np.testing.assert_allclose(dt.cpu().numpy(), td.grad.numpy(), rtol=1e-4, atol=2e-6 * max(scale, 1.0))
+    np.testing.assert_allclose(dg.cpu().numpy(), gd.grad.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bd.grad.numpy(), rtol=1e-5, atol=1e-4)
+    # the Linear bias in front of a BatchNorm has gradient sum(dt) = 0 up to rounding
+    assert float(dbias.abs().max()) <= 1e-5 * n * max(scale, 1.0)
+    # deterministic: same bits on a second run
+    y2, _, _ = hip.ops.bn_relu_forward(d(t), d(gamma), d(beta), 1e-5, 0.1, None, None, relu=relu)
+    assert torch.equal(y2, y)
+
+
+def test_relu_bias_backward_and_losses_match_torch(hip):
+    rs = _rs(11)
+    dev = torch.device(DEV)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    gy, y = gi.f32(rs.standard_normal((777, 200))), gi.f32(np.maximum(rs.standard_normal((777, 200)), 0))
+    g, db = hip.ops.relu_bias_backward(d(gy), d(y), relu=True)
+    want = gy * (y > 0)
+    assert np.array_equal(g.cpu().numpy(), want)
+    np.testing.assert_allclose(db.cpu().numpy(), want.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    g2, db2 = hip.ops.relu_bias_backward(d(gy), None, relu=False)
+    assert np.array_equal(g2.cpu().numpy(), gy)
+    np.testing.assert_allclose(db2.cpu().numpy(), gy.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    for kind, fn in (("mse", F.mse_loss), ("l1", F.l1_loss)):
+        out = torch.from_numpy(gi.f32(rs.standard_normal((513, 768)))).requires_grad_(True)
+        x = torch.from_numpy(gi.f32(rs.standard_normal((513, 768))))
+        ref = fn(out, x, reduction="mean")
+        ref.backward()
+        loss, grad = hip.ops.recon_loss_grad(out.detach().to(dev), x.to(dev), kind)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-6)
+        np.testing.assert_allclose(grad.cpu().numpy(), out.grad.numpy(), rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("decoupled,schedule", [(True, "linear"), (True, "constant"), (False, None)])
+def test_clip_and_adamw_match_torch(hip, decoupled, schedule):
+    """Five steps of clip_grad_norm_(1.0) + AdamW/Adam + warm-up schedule on a flat buffer against torch's own
+    (single-tensor, CPU) implementation and transformers' multipliers as restated in lcrec_amd.trainer."""
+    from lcrec_amd.trainer import constant_schedule_with_warmup, linear_schedule_with_warmup
+    rs = _rs(5)
+    n = 100_003
+    p0 = gi.f32(rs.standard_normal(n) * 0.1)
+    grads = [gi.f32(rs.standard_normal(n) * s) for s in (0.001, 0.01, 0.02, 1e-4, 0.003)]
+    pr = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    cls = torch.optim.AdamW if decoupled else torch.optim.Adam
+    opt = cls([pr], lr=1e-3, weight_decay=1e-4)
+    sched = {"linear": lambda: linear_schedule_with_warmup(opt, 2, 10), "constant": lambda: constant_schedule_with_warmup(opt, 2),
+             None: lambda: None}[schedule]()
+    dev = torch.device(DEV)
+    p = torch.from_numpy(p0.copy()).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros((), dtype=torch.int64, device=dev)
+    lr_used = torch.zeros((), dtype=torch.float32, device=dev)
+    for i, g in enumerate(grads):
+        pr.grad = torch.from_numpy(g.copy())
+        lr_ref = opt.param_groups[0]["lr"]
+        norm_ref = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        if sched is not None:
+            sched.step()
+        gd = torch.from_numpy(g.copy()).to(dev)
+        clip = hip.ops.grad_norm_clip(gd, 1.0)
+        hip.ops.adamw_step(p, gd, m, v, step, 1e-3, (0.9, 0.999), 1e-8, 1e-4, decoupled, clip=clip,
+                           schedule={"linear": 1, "constant": 0, None: -1}[schedule], warmup_steps=2, total_steps=10,
+                           lr_out=lr_used)
+        np.testing.assert_allclose(clip[0].item(), float(norm_ref), rtol=1e-6)
+        np.testing.assert_allclose(lr_used.item(), lr_ref, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(gd.cpu().numpy(), pr.grad.numpy(), rtol=1e-6, atol=1e-12)          # clipped in place
+        np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=2e-5, atol=1e-7, err_msg=f"step {i}")
+    assert int(step.item()) == len(grads)
+    st = opt.state[pr]
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
+
+
+def _tiny(hip, bn):
+    g = np.load(os.path.join(GOLD, f"f4_step_bn{bn}.npz"))
+    model = hip.RQVAE(in_dim=128, num_emb_list=[256] * 4, e_dim=16, layers=[64, 32], dropout_prob=0.0, bn=bool(bn),
+                      loss_type="mse", quant_loss_weight=1.0, beta=0.25, kmeans_init=False, kmeans_iters=100,
+                      sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+    sd = {k[4:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd__")}
+    model.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(gi.f32(gi.rs(400 + bn).standard_normal((256, 128)))).to(DEV)
+    return g, model.to(DEV), x
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("bn", [0, 1])
+def test_engine_reproduces_reference_trajectory(hip, bn, use_graph):
+    """F4: trainer.py:111-120 three times through the graph-captured step (step 1 eager, step 2 captured + replayed,
+    step 3 replayed) against the REFERENCE's recorded losses, gradient norm, learning rate, gradients and post-step
+    state -- the same assertions tests/test_gpu_modules.py makes for the autograd path."""
+    from lcrec_amd.engine import TrainEngine
+    from lcrec_amd.trainer import linear_schedule_with_warmup
+    g, model, x = _tiny(hip, bn)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    sched = linear_schedule_with_warmup(opt, num_warmup_steps=2, num_training_steps=10)
+    assert TrainEngine.unsupported_reason(model, opt) is None
+    eng = TrainEngine(model, opt, "linear", 2, 10, use_graph=use_graph)
+    traj = g["trajectory"]
+    for step in range(3):
+        eng.step(x)
+        loss, recon, rq_loss = eng.last.tolist()
+        got = [loss, recon, rq_loss, eng.clip[0].item()]
+        np.testing.assert_allclose(got, traj[step][:4], rtol=2e-5, atol=1e-12, err_msg=f"step {step}")
+        # traj[s][4] is the learning rate AFTER scheduler.step() of step s, i.e. the one step s + 1 uses
+        np.testing.assert_allclose(eng.lr_used.item(), 0.0 if step == 0 else traj[step - 1][4], rtol=1e-6, atol=1e-12)
+        if step == 0:
+            gmax = max(np.abs(g[f]).max() for f in g.files if f.startswith("grad__"))
+            coef = eng.clip[1].item()
+            for k, p in model.named_parameters():
+                np.testing.assert_allclose(p.grad.cpu().numpy() / coef, g["grad__" + k], rtol=1e-4, atol=1e-6 * gmax, err_msg=k)
+            for k, v in model.state_dict().items():
+                ref = g["step1__" + k]
+                if np.issubdtype(ref.dtype, np.floating):
+                    np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=1e-4, atol=2e-6, err_msg=k)
+                else:
+                    assert np.array_equal(v.cpu().numpy(), ref), k
+    total, recon_total = eng.end_epoch(sched)
+    np.testing.assert_allclose(total, traj[:, 0].astype(np.float64).sum(), rtol=2e-5)
+    assert eng.graph_replays == (2 if use_graph else 0)
+    assert sched.last_epoch == 3 and abs(sched.get_last_lr()[0] - 1e-3 * (10 - 3) / 8) < 1e-12
+    assert float(opt.state[next(model.parameters())]["step"]) == 3.0
+
+
+@pytest.mark.parametrize("bn", [False, True])
+def test_engine_equals_autograd_path_on_the_run_sh_architecture(hip, bn):
+    """Same model, same batches, four steps: the autograd path (torch BatchNorm / AdamW / clip) and the engine (own
+    kernels, one hipGraph) agree -- bit for bit in the forward GEMMs, to rounding where the op order differs."""
+    from lcrec_amd.engine import TrainEngine
+    torch.manual_seed(5)
+    xs = [torch.randn(512, 768, device=DEV) for _ in range(2)]
+
+    def build():
+        torch.manual_seed(7)
+        m = hip.RQVAE(in_dim=768, num_emb_list=[256] * 4, e_dim=32, layers=gi.RUN_SH_LAYERS, bn=bn, kmeans_init=False,
+                      sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50).to(DEV)
+        with torch.no_grad():
+            z = m.eval().encoder(xs[0])
+            for l, q in enumerate(m.rq.vq_layers):
+                q.embedding.weight.copy_(z[l * 256:(l + 1) * 256] * (0.6 ** l))
+        return m.train()
+
+    a, b = build(), build()
+    opt_a = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    opt_b = torch.optim.AdamW(b.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    eng = TrainEngine(b, opt_b, None, 0, 0)
+    losses = []
+    for step in range(4):
+        x = xs[step % 2]
+        opt_a.zero_grad()
+        out, rq_loss, idx = a(x)
+        loss, _ = a.compute_loss(out, rq_loss, xs=x)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0)
+        opt_a.step()
+        eng.step(x)
+        losses.append((loss.item(), eng.last[0].item()))
+    assert eng.graph_replays == 3
+    for la, lb in losses:
+        np.testing.assert_allclose(lb, la, rtol=1e-5)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            np.testing.assert_allclose(sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-3, atol=5e-6, err_msg=k)
+        else:
+            assert torch.equal(sa[k], sb[k]), k
+
+
+def test_trainer_uses_the_engine_and_matches_the_autograd_epochs(hip, tmp_path):
+    """Trainer.fit over a small dataset with a ragged last batch, engine on vs off: same epoch losses and collision
+    rate; the engine captured one graph per batch size and replayed it."""
+    from lcrec_amd import main as cli
+    from lcrec_amd.datasets import DeviceLoader
+    from lcrec_amd.trainer import Trainer
+    data = torch.from_numpy(gi.toy_items(3, n=1000, d=128)).to(DEV)
+    results = {}
+    for mode in ("auto", "off"):
+        argv = ["--data_path", "unused", "--ckpt_dir", str(tmp_path / mode), "--device", DEV, "--batch_size", "256",
+                "--epochs", "3", "--eval_step", "3", "--no_kmeans_init", "--num_emb_list", "32", "32", "32", "--e_dim", "32",
+                "--layers", "64", "--sk_epsilons", "0.0", "0.0", "0.003", "--train_engine", mode, "--bn", "True",
+                "--lr_scheduler_type", "linear", "--warmup_epochs", "1"]
+        args = cli.parse_args(argv)
+        cli.seed_everything(2024)
+        model = cli.build_model(args, 128)
+        loader = DeviceLoader(data, 256, True, DEV)
+        tr = Trainer(args, model, len(loader))
+        per_epoch = [tr._train_epoch(loader, e) for e in range(3)]
+        results[mode] = (per_epoch, tr._valid_epoch(loader), tr)
+    on, off = results["auto"], results["off"]
+    assert on[2].engine is not None and off[2].engine is None
+    assert on[2].engine.graph_replays == 3 * 4 - 2              # 4 batches/epoch (3 x 256 + 232); the first step at each of the two sizes is eager
+    for (la, ra), (lb, rb) in zip(on[0], off[0]):
+        np.testing.assert_allclose([la, ra], [lb, rb], rtol=1e-3)
+    assert abs(on[1] - off[1]) < 0.02
+    # a checkpoint written while the engine owns the parameters has the reference's layout and reloads
+    path = on[2]._save_checkpoint(epoch=2, ckpt_file="e.pth")
+    from lcrec_amd import generate_indices as gen
+    ck = gen.load_checkpoint(path)
+    assert sorted(ck) == ["args", "best_collision_rate", "best_loss", "epoch", "optimizer", "state_dict"]
+    fresh = cli.build_model(ck["args"], 128)
+    fresh.load_state_dict(ck["state_dict"])
+    for k, v in on[2].model.state_dict().items():
+        assert torch.equal(v.cpu(), fresh.state_dict()[k]), k
+    st = ck["optimizer"]["state"]
+    assert len(st) == len(list(model.parameters())) and float(st[0]["step"]) == 12.0

@@ -28,7 +28,7 @@ def trainer_probe(a):
         argv = ["--data_path", "unused", "--ckpt_dir", tmp, "--device", dev, "--batch_size", str(a.batch), "--epochs", "4",
                 "--no_kmeans_init", "--num_emb_list", "256", "256", "256", "256",          # run.sh: 4 levels, Sinkhorn on the last
                 "--sk_epsilons", "0.0", "0.0", "0.0", "0.0" if a.no_sk else "0.003"] \
-            + ([] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else [])
+            + ([] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else []) + ["--train_engine", a.engine]
         args = cli.parse_args(argv)
         cli.seed_everything(2024)
         model = cli.build_model(args, a.in_dim)
@@ -53,8 +53,10 @@ def trainer_probe(a):
             prof.disable()
             pstats.Stats(prof).sort_stats("tottime").print_stats(30)
         steps = epochs * len(loader)
-        print(f"Trainer._train_epoch: in_dim {a.in_dim} batch {a.batch} levels 4 sinkhorn {not a.no_sk} bn {a.bn} strict_nan_check {a.strict}: {dt / steps * 1e3:.3f} ms/step, "
-              f"{a.batch * steps / dt:,.0f} items/s")
+        eng = trainer.engine
+        print(f"Trainer._train_epoch: in_dim {a.in_dim} batch {a.batch} levels 4 sinkhorn {not a.no_sk} bn {a.bn} strict_nan_check {a.strict} "
+              f"engine {'hipGraph (%d replays)' % eng.graph_replays if eng is not None else 'off (autograd path)'}: "
+              f"{dt / steps * 1e3:.3f} ms/step, {a.batch * steps / dt:,.0f} items/s")
 
 
 def main():
@@ -67,6 +69,7 @@ def main():
     ap.add_argument("--no_sk", action="store_true")
     ap.add_argument("--strict", action="store_true", help="with --trainer: the per-step NaN host sync of the reference")
     ap.add_argument("--cprofile", action="store_true", help="with --trainer: cProfile of the timed epochs")
+    ap.add_argument("--engine", default="auto", choices=["auto", "off"], help="with --trainer: --train_engine of lcrec_amd.main")
     ap.add_argument("--trainer", action="store_true",
                     help="time lcrec_amd.trainer.Trainer._train_epoch itself (loader, NaN check, fused AdamW, schedule)")
     a = ap.parse_args()
