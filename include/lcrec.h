@@ -256,6 +256,22 @@ int lcrec_bn_relu_backward(const float *gy, const float *t, const float *y, int6
                            const float *mean, const float *rstd, int relu, float *dt_out, float *dgamma_out,
                            float *dbeta_out, float *dbias_out, void *stream);
 
+/* The same two operations split where an item-sharded (data-parallel) run exchanges statistics, so that the batch is the
+ * union of all ranks' rows (torch.nn.SyncBatchNorm semantics; the reference's index/ stage is single-process, SURVEY.md
+ * section 8e item 4):
+ *   lcrec_bn_stats            local mean and M2 = sum (t - mean)^2 of this rank's n rows      -> merged over ranks by the caller
+ *   lcrec_bn_relu_apply       y = [relu]((t - mean) * rstd * gamma + beta) with the merged statistics
+ *   lcrec_bn_backward_reduce  local sum g and sum g*xhat (g = gy * [y > 0])                    -> all-reduced by the caller
+ *   lcrec_bn_backward_apply   dt = gamma*rstd*(g - sum_g/n_total - xhat*sum_gx/n_total), dbias = local column sums of dt */
+int lcrec_bn_stats(const float *t, int64_t n, int features, float *mean_out, float *m2_out, void *stream);
+int lcrec_bn_relu_apply(const float *t, int64_t n, int features, const float *gamma, const float *beta, const float *mean,
+                        const float *rstd, int relu, float *y, void *stream);
+int lcrec_bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int features, const float *mean,
+                             const float *rstd, int relu, float *sum_g_out, float *sum_gx_out, void *stream);
+int lcrec_bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
+                            const float *mean, const float *rstd, int relu, const float *sum_g, const float *sum_gx,
+                            float n_total, float *dt_out, float *dbias_out, void *stream);
+
 /* ReLU mask and bias gradient of a Linear without BatchNorm (layers.py:23,28-30): g = gy * [y > 0] (relu != 0;
  * g_out may alias gy or be NULL), dbias = column sums of g. */
 int lcrec_relu_bias_backward(const float *gy, const float *y, int64_t n, int features, int relu, float *g_out,
@@ -275,6 +291,12 @@ int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int l
  * lcrec_adamw_step applies. */
 int lcrec_grad_norm_clip(const float *grads, int64_t count, float max_norm, float *norm_out, void *workspace,
                          size_t workspace_bytes, void *stream);
+
+/* Codebook gradient from the per-code statistics of lcrec_code_stats -- what autograd derives from the two MSE terms
+ * of index/models/vq.py:90-92: grad[k][:] = (scale * (count[k]*C[k][:] - sum[k][:])) * weight, with
+ * scale = 2/(L*n*e) and weight = d loss / d rq_loss (quant_loss_weight, index/models/rqvae.py:83).  [K][e] each. */
+int lcrec_codebook_grad(const float *count, const float *sum, const float *codebook, int K, int e, float scale,
+                        float weight, float *grad_out, void *stream);
 
 /* One optimiser step on flat fp32 buffers: torch.optim.AdamW (decoupled != 0) or Adam (index/trainer.py:49-81,119),
  * preceded by the clipping of index/trainer.py:118 (grads *= clip[1], stored back; clip may be NULL) and with the

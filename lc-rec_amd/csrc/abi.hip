@@ -411,3 +411,34 @@ LCREC_API int lcrec_adamw_step(float *params, float *grads, float *exp_avg, floa
     return adamw_step(params, grads, exp_avg, exp_avg_sq, count, clip, step, base_lr, beta1, beta2, eps, weight_decay, decoupled,
                       schedule, warmup_steps, total_steps, lr_out, (hipStream_t)stream);
 }
+
+LCREC_API int lcrec_codebook_grad(const float *count, const float *sum, const float *codebook, int K, int e, float scale,
+                                  float weight, float *grad_out, void *stream)
+{
+    return codebook_grad(count, sum, codebook, K, e, scale, weight, grad_out, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_bn_stats(const float *t, int64_t n, int features, float *mean_out, float *m2_out, void *stream)
+{
+    return bn_stats(t, n, features, mean_out, m2_out, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_bn_relu_apply(const float *t, int64_t n, int features, const float *gamma, const float *beta, const float *mean,
+                                  const float *rstd, int relu, float *y, void *stream)
+{
+    return bn_relu_apply(t, n, features, gamma, beta, mean, rstd, relu, y, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int features, const float *mean,
+                                       const float *rstd, int relu, float *sum_g_out, float *sum_gx_out, void *stream)
+{
+    return bn_backward_reduce(gy, t, y, n, features, mean, rstd, relu, sum_g_out, sum_gx_out, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
+                                      const float *mean, const float *rstd, int relu, const float *sum_g, const float *sum_gx,
+                                      float n_total, float *dt_out, float *dbias_out, void *stream)
+{
+    return bn_backward_apply(gy, t, y, n, features, gamma, mean, rstd, relu, sum_g, sum_gx, n_total, dt_out, dbias_out,
+                             (hipStream_t)stream);
+}

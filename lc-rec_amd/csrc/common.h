@@ -137,12 +137,22 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
                     hipStream_t stream);
 int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
                      const float *rstd, int relu, float *dt, float *dgamma, float *dbeta, float *dbias, hipStream_t stream);
+int bn_stats(const float *t, int64_t n, int F, float *mean_out, float *m2_out, hipStream_t stream);
+int bn_relu_apply(const float *t, int64_t n, int F, const float *gamma, const float *beta, const float *mean, const float *rstd,
+                  int relu, float *y, hipStream_t stream);
+int bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int F, const float *mean, const float *rstd,
+                       int relu, float *sum_g, float *sum_gx, hipStream_t stream);
+int bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
+                      const float *rstd, int relu, const float *sum_g, const float *sum_gx, float n_total, float *dt, float *dbias,
+                      hipStream_t stream);
 int relu_bias_backward(const float *gy, const float *y, int64_t n, int F, int relu, float *g_out, float *dbias, hipStream_t stream);
 size_t train_reduce_workspace();
 int recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *g, float *loss, void *workspace,
                     size_t workspace_bytes, hipStream_t stream);
 int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_out, void *workspace, size_t workspace_bytes,
                    hipStream_t stream);
+int codebook_grad(const float *count, const float *sum, const float *cb, int K, int e, float scale, float weight, float *grad,
+                  hipStream_t stream);
 int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const float *clip, int64_t *step, double base_lr,
                double beta1, double beta2, double eps, double weight_decay, int decoupled, int schedule, int64_t warmup_steps,
                int64_t total_steps, float *lr_out, hipStream_t stream);

@@ -11,61 +11,121 @@
 //                      (trainer.py:49-92,119-120)
 //
 // All of it is HBM/L2-bound streaming over [batch][features] or over the flat parameter buffer; no MFMA.  Column
-// reductions (BatchNorm statistics, bias gradients) are done by one workgroup per strip of 32 columns: 8 row groups of
-// 32 lanes read 128-byte row segments (coalesced), each lane sums its rows in order, the 8 partials are added in a fixed
-// order through LDS -- deterministic, no atomics.  Batch-sized inputs only (a training batch is 1-8 k rows; the whole
-// strip is re-read from L2 for the second pass).
+// reductions (BatchNorm statistics, bias gradients) are done by one 1024-thread workgroup per strip of 8-32 columns
+// (see Strip below): deterministic, no atomics.  Batch-sized inputs only (a training batch is 1-8 k rows; the strip is
+// re-read from L2 for the later passes).  First form (256 threads, one load in flight per lane): 64 us per call at
+// 1024 x 2048 -- a third of the training step; 16 waves with 8 loads in flight each: see profiles/.
 #include "common.h"
 
 namespace lcrec {
 
-constexpr int COLS = 32;          // columns per workgroup
-constexpr int RGS = 8;            // row groups per workgroup
-constexpr int CR_THREADS = COLS * RGS;
+constexpr int CR_THREADS = 1024;  // 16 waves per strip: enough loads in flight to cover HBM/L2 latency from one CU
+constexpr int CR_WAVES = CR_THREADS / 64;
+constexpr int CR_UNROLL = 8;
 
-// sum over the RGS row groups of one value per (row group, column); result valid in every thread of the column
-__device__ __forceinline__ float strip_sum(float v, float (*sm)[COLS], int rg, int c)
-{
-    __syncthreads();                       // previous use of sm is over
-    sm[rg][c] = v;
-    __syncthreads();
-    float s = sm[0][c];
+// Strip geometry: COLS columns x RGS = 1024 / COLS row groups; lane l of a wave holds column l % COLS, so a wave spans
+// 64 / COLS consecutive row groups.  Row group g owns rows g, g + RGS, ... (each lane adds its rows in ascending order,
+// CR_UNROLL loads in flight); the groups of a wave are added by xor-shuffles (a fixed tree), the 16 waves through LDS in
+// wave order -- the same bits on every run.
+template <int COLS>
+struct Strip {
+    static constexpr int RGS = CR_THREADS / COLS;
+    int c, rg, col;
+    bool live;
+    __device__ Strip(int F) : c(threadIdx.x % COLS), rg(threadIdx.x / COLS), col(blockIdx.x * COLS + threadIdx.x % COLS), live(col < F) {}
+
+    // f(row) -> value; returns the sum over this lane's rows in ascending row order
+    template <typename Fn>
+    __device__ __forceinline__ float rows(int64_t n, Fn f) const
+    {
+        float s = 0.f;
+        int64_t r = rg;
+        for (; r + (int64_t)(CR_UNROLL - 1) * RGS < n; r += (int64_t)CR_UNROLL * RGS) {
+            float v[CR_UNROLL];
 #pragma unroll
-    for (int g = 1; g < RGS; ++g) s += sm[g][c];
-    return s;
-}
+            for (int u = 0; u < CR_UNROLL; ++u) v[u] = f(r + (int64_t)u * RGS);
+#pragma unroll
+            for (int u = 0; u < CR_UNROLL; ++u) s += v[u];
+        }
+        for (; r < n; r += RGS) s += f(r);
+        return s;
+    }
+
+    // the same walk with two running sums: f(row, a, b) adds the row's contribution to both
+    template <typename Fn>
+    __device__ __forceinline__ void rows2(int64_t n, float &s0, float &s1, Fn f) const
+    {
+        s0 = 0.f;
+        s1 = 0.f;
+        int64_t r = rg;
+        for (; r + (int64_t)(CR_UNROLL - 1) * RGS < n; r += (int64_t)CR_UNROLL * RGS) {
+            float v0[CR_UNROLL], v1[CR_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CR_UNROLL; ++u) f(r + (int64_t)u * RGS, v0[u], v1[u]);
+#pragma unroll
+            for (int u = 0; u < CR_UNROLL; ++u) { s0 += v0[u]; s1 += v1[u]; }
+        }
+        for (; r < n; r += RGS) {
+            float a, b;
+            f(r, a, b);
+            s0 += a;
+            s1 += b;
+        }
+    }
+
+    // sum of one value per lane over all row groups of the lane's column; valid in every lane
+    __device__ __forceinline__ float sum(float v, float (*sm)[COLS]) const
+    {
+#pragma unroll
+        for (int o = COLS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();                       // previous use of sm is over
+        if ((threadIdx.x & 63) < COLS) sm[threadIdx.x >> 6][c] = v;
+        __syncthreads();
+        float s = sm[0][c];
+#pragma unroll
+        for (int w = 1; w < CR_WAVES; ++w) s += sm[w][c];
+        return s;
+    }
+};
 
 // Training-mode BatchNorm1d (+ReLU).  torch semantics: batch mean, biased variance for the normalisation,
 // running_mean/var updated with `momentum` (running_var from the unbiased variance), eps inside the square root.
+template <int COLS>
 __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_kernel(const float *__restrict__ t, int64_t n, int F,
                                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                       float eps, float momentum, float *running_mean,
                                                                       float *running_var, float *__restrict__ y, float *mean_out,
                                                                       float *rstd_out, int relu)
 {
-    __shared__ float sm[RGS][COLS];
-    const int c = threadIdx.x % COLS, rg = threadIdx.x / COLS;
-    const int col = blockIdx.x * COLS + c;
-    const bool live = col < F;
+    __shared__ float sm[CR_WAVES][COLS];
+    const Strip<COLS> st(F);
+    const int col = st.live ? st.col : 0;          // dead lanes read column 0 and write nothing
     const float inv_n = 1.0f / (float)n;
-    float s = 0.f;
-    if (live)
-        for (int64_t r = rg; r < n; r += RGS) s += t[r * F + col];
-    const float mean = strip_sum(s, sm, rg, c) * inv_n;
-    float q = 0.f;
-    if (live)
-        for (int64_t r = rg; r < n; r += RGS) { const float d = t[r * F + col] - mean; q = __builtin_fmaf(d, d, q); }
-    const float m2 = strip_sum(q, sm, rg, c);
+    const float *tc = t + col;
+    // one statistics pass: sums of (t - pivot) and (t - pivot)^2 with pivot = the column's first row, a sample of the
+    // column -- so |mean - pivot| is of the order of the standard deviation and m2 = s2 - s1^2/n loses a bit or two, not
+    // the digits the textbook E[t^2] - mean^2 loses when |mean| >> std
+    const float pivot = tc[0];
+    float s1, s2;
+    st.rows2(n, s1, s2, [&](int64_t r, float &a, float &b) { const float d = tc[r * F] - pivot; a = d; b = d * d; });
+    s1 = st.sum(s1, sm);
+    s2 = st.sum(s2, sm);
+    const float dmean = s1 * inv_n;
+    const float mean = pivot + dmean;
+    float m2 = s2 - s1 * dmean;
+    m2 = m2 > 0.f ? m2 : 0.f;
     const float var = m2 * inv_n;
     const float rstd = 1.0f / __builtin_sqrtf(var + eps);
-    if (!live) return;
+    if (!st.live) return;
     const float g = gamma ? gamma[col] : 1.0f, b = beta ? beta[col] : 0.0f;
-    for (int64_t r = rg; r < n; r += RGS) {
-        float v = (t[r * F + col] - mean) * rstd * g + b;
+    float *yc = y + col;
+#pragma unroll 4
+    for (int64_t r = st.rg; r < n; r += Strip<COLS>::RGS) {
+        float v = (tc[r * F] - mean) * rstd * g + b;
         if (relu) v = v > 0.f ? v : 0.f;
-        y[r * F + col] = v;
+        yc[r * F] = v;
     }
-    if (rg == 0) {
+    if (st.rg == 0) {
         mean_out[col] = mean;
         rstd_out[col] = rstd;
         if (running_mean) running_mean[col] = (1.0f - momentum) * running_mean[col] + momentum * mean;
@@ -79,66 +139,155 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_kernel(const float
 // Backward of y = [relu](bn(t)) for gy = dL/dy:
 //   g = gy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;  dt = gamma * rstd * (g - dbeta/n - xhat * dgamma/n)
 // and the gradient of the Linear bias that produced t: dbias = sum dt (zero up to rounding, as in autograd).
-__global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const float *__restrict__ gy, const float *__restrict__ t,
+template <int COLS>
+__global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const float *gy, const float *__restrict__ t,
                                                                        const float *__restrict__ y, int64_t n, int F,
                                                                        const float *__restrict__ gamma, const float *__restrict__ mean,
-                                                                       const float *__restrict__ rstd, int relu, float *__restrict__ dt,
+                                                                       const float *__restrict__ rstd, int relu, float *dt,
                                                                        float *dgamma, float *dbeta, float *dbias)
 {
-    __shared__ float sm[RGS][COLS];
-    const int c = threadIdx.x % COLS, rg = threadIdx.x / COLS;
-    const int col = blockIdx.x * COLS + c;
-    const bool live = col < F;
-    const float mu = live ? mean[col] : 0.f, rs = live ? rstd[col] : 0.f, gm = live ? (gamma ? gamma[col] : 1.0f) : 0.f;
-    float sg = 0.f, sgx = 0.f;
-    if (live)
-        for (int64_t r = rg; r < n; r += RGS) {
-            float g = gy[r * F + col];
-            if (relu && !(y[r * F + col] > 0.f)) g = 0.f;
-            const float xh = (t[r * F + col] - mu) * rs;
-            sg += g;
-            sgx = __builtin_fmaf(g, xh, sgx);
-        }
-    const float db = strip_sum(sg, sm, rg, c);
-    const float dg = strip_sum(sgx, sm, rg, c);
+    __shared__ float sm[CR_WAVES][COLS];
+    const Strip<COLS> st(F);
+    const int col = st.live ? st.col : 0;
+    const float mu = mean[col], rs = rstd[col], gm = gamma ? gamma[col] : 1.0f;
+    const float *gc = gy + col, *tc = t + col, *yc = relu ? y + col : nullptr;
+    auto gval = [&](int64_t r) { float g = gc[r * F]; if (relu && !(yc[r * F] > 0.f)) g = 0.f; return g; };
+    float db, dg;
+    st.rows2(n, db, dg, [&](int64_t r, float &a, float &b) { const float g = gval(r); a = g; b = g * ((tc[r * F] - mu) * rs); });
+    db = st.sum(db, sm);
+    dg = st.sum(dg, sm);
     const float inv_n = 1.0f / (float)n;
     const float k = gm * rs, mdb = db * inv_n, mdg = dg * inv_n;
+    float *dc = dt + col;
     float sdt = 0.f;
-    if (live)
-        for (int64_t r = rg; r < n; r += RGS) {
-            float g = gy[r * F + col];
-            if (relu && !(y[r * F + col] > 0.f)) g = 0.f;
-            const float xh = (t[r * F + col] - mu) * rs;
-            const float v = k * (g - mdb - xh * mdg);
-            dt[r * F + col] = v;
+    if (st.live) {
+#pragma unroll 4
+        for (int64_t r = st.rg; r < n; r += Strip<COLS>::RGS) {
+            const float xh = (tc[r * F] - mu) * rs;
+            const float v = k * (gval(r) - mdb - xh * mdg);
+            dc[r * F] = v;
             sdt += v;
         }
-    const float dbs = strip_sum(sdt, sm, rg, c);
-    if (live && rg == 0) {
+    }
+    const float dbs = st.sum(sdt, sm);
+    if (st.live && st.rg == 0) {
         if (dgamma) dgamma[col] = dg;
         if (dbeta) dbeta[col] = db;
         if (dbias) dbias[col] = dbs;
     }
 }
 
+// ---- the same, split at the points where a data-parallel run exchanges statistics (SyncBatchNorm semantics: the
+// batch is the union of the ranks' rows; lcrec_amd/layers.py all-reduces between the halves)
+//
+// local statistics of a rank's rows: mean and M2 = sum (t - mean)^2, to be merged over ranks (Chan et al.)
+template <int COLS>
+__global__ __launch_bounds__(CR_THREADS) void bn_stats_kernel(const float *__restrict__ t, int64_t n, int F, float *mean_out, float *m2_out)
+{
+    __shared__ float sm[CR_WAVES][COLS];
+    const Strip<COLS> st(F);
+    const int col = st.live ? st.col : 0;
+    const float *tc = t + col;
+    const float pivot = tc[0];
+    float s1, s2;
+    st.rows2(n, s1, s2, [&](int64_t r, float &a, float &b) { const float d = tc[r * F] - pivot; a = d; b = d * d; });
+    s1 = st.sum(s1, sm);
+    s2 = st.sum(s2, sm);
+    const float dmean = s1 / (float)n;
+    float m2 = s2 - s1 * dmean;
+    m2 = m2 > 0.f ? m2 : 0.f;
+    if (st.live && st.rg == 0) { mean_out[col] = pivot + dmean; m2_out[col] = m2; }
+}
+
+// y = [relu]((t - mean) * rstd * gamma + beta) with given (global) statistics
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float *__restrict__ t, int64_t n, int F, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, int relu, float *__restrict__ y)
+{
+    const int64_t total = n * F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % F);
+        float v = (t[i] - mean[col]) * rstd[col] * (gamma ? gamma[col] : 1.0f) + (beta ? beta[col] : 0.0f);
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[i] = v;
+    }
+}
+
+// local sums of the backward: sum g and sum g * xhat over this rank's rows (g = gy * [y > 0], xhat from the GLOBAL statistics)
+template <int COLS>
+__global__ __launch_bounds__(CR_THREADS) void bn_backward_reduce_kernel(const float *__restrict__ gy, const float *__restrict__ t,
+                                                                        const float *__restrict__ y, int64_t n, int F,
+                                                                        const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                        int relu, float *sum_g, float *sum_gx)
+{
+    __shared__ float sm[CR_WAVES][COLS];
+    const Strip<COLS> st(F);
+    const int col = st.live ? st.col : 0;
+    const float mu = mean[col], rs = rstd[col];
+    const float *gc = gy + col, *tc = t + col, *yc = relu ? y + col : nullptr;
+    float db, dg;
+    st.rows2(n, db, dg, [&](int64_t r, float &a, float &b) {
+        float g = gc[r * F];
+        if (relu && !(yc[r * F] > 0.f)) g = 0.f;
+        a = g;
+        b = g * ((tc[r * F] - mu) * rs);
+    });
+    db = st.sum(db, sm);
+    dg = st.sum(dg, sm);
+    if (st.live && st.rg == 0) { sum_g[col] = db; sum_gx[col] = dg; }
+}
+
+// dt = gamma * rstd * (g - sum_g / n_total - xhat * sum_gx / n_total) with the GLOBAL sums; dbias = local column sums of dt
+template <int COLS>
+__global__ __launch_bounds__(CR_THREADS) void bn_backward_apply_kernel(const float *gy, const float *__restrict__ t,
+                                                                       const float *__restrict__ y, int64_t n, int F,
+                                                                       const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                                       const float *__restrict__ rstd, int relu,
+                                                                       const float *__restrict__ sum_g, const float *__restrict__ sum_gx,
+                                                                       float n_total, float *dt, float *dbias)
+{
+    __shared__ float sm[CR_WAVES][COLS];
+    const Strip<COLS> st(F);
+    const int col = st.live ? st.col : 0;
+    const float mu = mean[col], rs = rstd[col], gm = gamma ? gamma[col] : 1.0f;
+    const float *gc = gy + col, *tc = t + col, *yc = relu ? y + col : nullptr;
+    const float inv_n = 1.0f / n_total;
+    const float k = gm * rs, mdb = sum_g[col] * inv_n, mdg = sum_gx[col] * inv_n;
+    float *dc = dt + col;
+    float sdt = 0.f;
+    if (st.live) {
+#pragma unroll 4
+        for (int64_t r = st.rg; r < n; r += Strip<COLS>::RGS) {
+            float g = gc[r * F];
+            if (relu && !(yc[r * F] > 0.f)) g = 0.f;
+            const float xh = (tc[r * F] - mu) * rs;
+            const float v = k * (g - mdb - xh * mdg);
+            dc[r * F] = v;
+            sdt += v;
+        }
+    }
+    const float dbs = st.sum(sdt, sm);
+    if (st.live && st.rg == 0 && dbias) dbias[col] = dbs;
+}
+
 // g = gy * [y > 0] (in place allowed), dbias = column sums of g
+template <int COLS>
 __global__ __launch_bounds__(CR_THREADS) void relu_bias_backward_kernel(const float *gy, const float *__restrict__ y, int64_t n, int F,
                                                                          int relu, float *g_out, float *dbias)
 {
-    __shared__ float sm[RGS][COLS];
-    const int c = threadIdx.x % COLS, rg = threadIdx.x / COLS;
-    const int col = blockIdx.x * COLS + c;
-    const bool live = col < F;
-    float s = 0.f;
-    if (live)
-        for (int64_t r = rg; r < n; r += RGS) {
-            float g = gy[r * F + col];
-            if (relu && !(y[r * F + col] > 0.f)) g = 0.f;
-            if (g_out) g_out[r * F + col] = g;
-            s += g;
-        }
-    const float db = strip_sum(s, sm, rg, c);
-    if (live && rg == 0 && dbias) dbias[col] = db;
+    __shared__ float sm[CR_WAVES][COLS];
+    const Strip<COLS> st(F);
+    const int col = st.live ? st.col : 0;
+    const float *gc = gy + col, *yc = relu ? y + col : nullptr;
+    float *oc = (g_out && st.live) ? g_out + col : nullptr;
+    const float s = st.rows(n, [&](int64_t r) {
+        float g = gc[r * F];
+        if (relu && !(yc[r * F] > 0.f)) g = 0.f;
+        if (oc) oc[r * F] = g;
+        return g;
+    });
+    const float db = st.sum(s, sm);
+    if (st.live && st.rg == 0 && dbias) dbias[col] = db;
 }
 
 // ---- whole-tensor reductions: per-workgroup fp64 partials, then one finishing workgroup (fixed order)
@@ -280,9 +429,31 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(AdamParams a)
 
 __global__ void step_advance_kernel(int64_t *step) { *step += 1; }
 
+// dL/dC[k][:] = (scale * (count[k] * C[k][:] - sum[k][:])) * weight -- the closed form autograd derives from vq.py:90-92
+// (SURVEY.md a9), in the order quantize.py evaluates it
+__global__ __launch_bounds__(256) void codebook_grad_kernel(const float *__restrict__ count, const float *__restrict__ sum,
+                                                            const float *__restrict__ cb, int K, int e, float scale, float weight,
+                                                            float *__restrict__ grad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * e) return;
+    const float t = count[i / e] * cb[i] - sum[i];
+    grad[i] = (scale * t) * weight;
+}
+
 // ---------------------------------------------------------------- host side
 
-static int strips(int F) { return (F + COLS - 1) / COLS; }
+// strip width by feature count: wide layers read 128-byte row segments; narrow ones take narrower strips so that more
+// than a handful of CUs work (their whole input is a few hundred KB)
+static int strip_cols(int F) { return F >= 1024 ? 32 : (F >= 256 ? 16 : 8); }
+#define LCREC_STRIP_LAUNCH(KERN, F, stream, ...)                                                                      \
+    do {                                                                                                              \
+        const int cols_ = strip_cols(F);                                                                              \
+        const dim3 grid_((unsigned)(((F) + cols_ - 1) / cols_));                                                      \
+        if (cols_ == 32) hipLaunchKernelGGL(KERN<32>, grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);               \
+        else if (cols_ == 16) hipLaunchKernelGGL(KERN<16>, grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);          \
+        else hipLaunchKernelGGL(KERN<8>, grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);                            \
+    } while (0)
 
 int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const float *beta, float eps, float momentum,
                     float *running_mean, float *running_var, float *y, float *mean_out, float *rstd_out, int relu,
@@ -293,8 +464,8 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
     if (n < 2) return fail(LCREC_EINVAL, "bn_relu_forward: training-mode BatchNorm needs more than 1 row (n=%lld)", (long long)n);
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_forward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_FWD, stream);
-    hipLaunchKernelGGL(bn_relu_forward_kernel, dim3(strips(F)), dim3(CR_THREADS), 0, stream, t, n, F, gamma, beta, eps, momentum,
-                       running_mean, running_var, y, mean_out, rstd_out, relu);
+    LCREC_STRIP_LAUNCH(bn_relu_forward_kernel, F, stream, t, n, F, gamma, beta, eps, momentum, running_mean, running_var, y,
+                       mean_out, rstd_out, relu);
     return check_launch("bn_relu_forward_kernel");
 }
 
@@ -305,9 +476,50 @@ int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n,
     if (!gy || !t || !mean || !rstd || !dt || (relu && !y)) return fail(LCREC_EINVAL, "bn_relu_backward: NULL pointer");
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_backward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_BWD, stream);
-    hipLaunchKernelGGL(bn_relu_backward_kernel, dim3(strips(F)), dim3(CR_THREADS), 0, stream, gy, t, y, n, F, gamma, mean, rstd, relu,
-                       dt, dgamma, dbeta, dbias);
+    LCREC_STRIP_LAUNCH(bn_relu_backward_kernel, F, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias);
     return check_launch("bn_relu_backward_kernel");
+}
+
+int bn_stats(const float *t, int64_t n, int F, float *mean_out, float *m2_out, hipStream_t stream)
+{
+    if (!t || !mean_out || !m2_out) return fail(LCREC_EINVAL, "bn_stats: NULL pointer");
+    if (n < 1 || n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_stats: sized for training batches (n=%lld)", (long long)n);
+    TraceScope trace(K_BN_FWD, stream);
+    LCREC_STRIP_LAUNCH(bn_stats_kernel, F, stream, t, n, F, mean_out, m2_out);
+    return check_launch("bn_stats_kernel");
+}
+
+int bn_relu_apply(const float *t, int64_t n, int F, const float *gamma, const float *beta, const float *mean, const float *rstd,
+                  int relu, float *y, hipStream_t stream)
+{
+    if (n == 0 || F == 0) return LCREC_OK;
+    if (!t || !mean || !rstd || !y) return fail(LCREC_EINVAL, "bn_relu_apply: NULL pointer");
+    int64_t blocks = (n * F + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    TraceScope trace(K_BN_FWD, stream);
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, n, F, gamma, beta, mean, rstd, relu, y);
+    return check_launch("bn_relu_apply_kernel");
+}
+
+int bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int F, const float *mean, const float *rstd,
+                       int relu, float *sum_g, float *sum_gx, hipStream_t stream)
+{
+    if (!gy || !t || !mean || !rstd || !sum_g || !sum_gx || (relu && !y)) return fail(LCREC_EINVAL, "bn_backward_reduce: NULL pointer");
+    if (n < 1 || n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_backward_reduce: sized for training batches");
+    TraceScope trace(K_BN_BWD, stream);
+    LCREC_STRIP_LAUNCH(bn_backward_reduce_kernel, F, stream, gy, t, y, n, F, mean, rstd, relu, sum_g, sum_gx);
+    return check_launch("bn_backward_reduce_kernel");
+}
+
+int bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
+                      const float *rstd, int relu, const float *sum_g, const float *sum_gx, float n_total, float *dt, float *dbias,
+                      hipStream_t stream)
+{
+    if (!gy || !t || !mean || !rstd || !sum_g || !sum_gx || !dt || (relu && !y)) return fail(LCREC_EINVAL, "bn_backward_apply: NULL pointer");
+    if (n < 1 || n > (1 << 20) || F < 1 || !(n_total >= 1.0f)) return fail(LCREC_EUNSUPPORTED, "bn_backward_apply: sized for training batches");
+    TraceScope trace(K_BN_BWD, stream);
+    LCREC_STRIP_LAUNCH(bn_backward_apply_kernel, F, stream, gy, t, y, n, F, gamma, mean, rstd, relu, sum_g, sum_gx, n_total, dt, dbias);
+    return check_launch("bn_backward_apply_kernel");
 }
 
 int relu_bias_backward(const float *gy, const float *y, int64_t n, int F, int relu, float *g_out, float *dbias, hipStream_t stream)
@@ -316,7 +528,7 @@ int relu_bias_backward(const float *gy, const float *y, int64_t n, int F, int re
     if (!gy || (relu && !y)) return fail(LCREC_EINVAL, "relu_bias_backward: NULL pointer");
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "relu_bias_backward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_RELU_BIAS_BWD, stream);
-    hipLaunchKernelGGL(relu_bias_backward_kernel, dim3(strips(F)), dim3(CR_THREADS), 0, stream, gy, y, n, F, relu, g_out, dbias);
+    LCREC_STRIP_LAUNCH(relu_bias_backward_kernel, F, stream, gy, y, n, F, relu, g_out, dbias);
     return check_launch("relu_bias_backward_kernel");
 }
 
@@ -352,6 +564,16 @@ int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_ou
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, g, count, (double *)workspace);
     hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, max_norm, norm_out);
     return check_launch("grad_norm kernels");
+}
+
+int codebook_grad(const float *count, const float *sum, const float *cb, int K, int e, float scale, float weight, float *grad,
+                  hipStream_t stream)
+{
+    if (!count || !sum || !cb || !grad) return fail(LCREC_EINVAL, "codebook_grad: NULL pointer");
+    if (K < 1 || e < 1) return fail(LCREC_EINVAL, "codebook_grad: bad shape");
+    TraceScope trace(K_CODE_STATS, stream);
+    hipLaunchKernelGGL(codebook_grad_kernel, dim3((K * e + 255) / 256), dim3(256), 0, stream, count, sum, cb, K, e, scale, weight, grad);
+    return check_launch("codebook_grad_kernel");
 }
 
 int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const float *clip, int64_t *step, double base_lr,

@@ -990,6 +990,11 @@ static bool launch_skp(const SkPersist &p, hipStream_t stream)
     return true;
 }
 
+__global__ void sk_ctrl_init_kernel(unsigned *ctrl)
+{
+    if (threadIdx.x < 8) ctrl[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
+}
+
 static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K, double eps, int iters,
                         int64_t *idx_out, int64_t idx_stride, char *ws, hipStream_t stream)
 {
@@ -1006,10 +1011,11 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     ws += align_up((size_t)nblk * sizeof(double), 256);
     unsigned *minmax = reinterpret_cast<unsigned *>(ws);
     p.d = d; p.minmax = minmax; p.B = B; p.K = K; p.nblk = (int)nblk; p.eps = eps;
-    // {ord(min) = 0xffffffff, ord(max) = 0, barrier counter = 0, timeout flag = 0}: two memset nodes, no host buffer
-    hipError_t he = hipMemsetAsync(minmax, 0, 32, stream);
-    if (he == hipSuccess) he = hipMemsetAsync(minmax, 0xff, sizeof(unsigned), stream);
-    if (he != hipSuccess) return fail(LCREC_EHIP, "sinkhorn: %s", hipGetErrorString(he));
+    // {ord(min) = 0xffffffff, ord(max) = 0, barrier counter = 0, timeout flag = 0}
+    // by a kernel, not by memset nodes: inside a captured hipGraph (engine.py) the two memsets were seen to take effect
+    // late -- replays found the previous solve's flag / a counter reset under a running barrier
+    hipLaunchKernelGGL(sk_ctrl_init_kernel, dim3(1), dim3(64), 0, stream, minmax);
+    if (int rc0 = check_launch("sk_ctrl_init_kernel")) return rc0;
     int rc = vq_distances(r, B, e, cb, K, d, minmax, stream);
     if (rc) return rc;
     if (iters == 0) return fail(LCREC_EUNSUPPORTED, "sinkhorn: iters must be >= 1");

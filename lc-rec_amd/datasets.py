@@ -101,6 +101,7 @@ class DeviceLoader:
                 batch = self.data[lo:hi]
             else:
                 batch = self.data.index_select(0, order[lo:hi])
+            self.last_global_rows = hi - lo
             if self.world_size > 1:
                 # item-sharded data parallel: every rank walks the same global batch and keeps its slice
                 m = batch.shape[0]

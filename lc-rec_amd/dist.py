@@ -8,14 +8,21 @@ the concatenated batch:
   encode+assign / index generation   no collective: contiguous item ranges per rank, weights and
                                      codebooks replicated; index rows are gathered once at the end.
   training step
-    gradients      ONE flat fp32 all-reduce per step of [grads * n_local ..., n_local]; dividing by the
-                   summed n_local gives the gradient of the global-batch mean loss.  This covers the
-                   codebook gradients too: they are linear in the per-code (count, sum) statistics.
+    gradients      every rank back-propagates loss_r * n_r / N (n_r its rows, N the global batch), so the SUM of the
+                   ranks' gradients is the gradient of the global-batch mean loss -- also through the batch
+                   statistics of BatchNorm, whose backward sums over ranks (GradReducer below).  The parameters'
+                   .grad are views of ONE persistent flat buffer; it is all-reduced in buckets, each launched
+                   asynchronously from a backward hook the moment its last gradient has been accumulated, so the
+                   decoder's buckets travel while the encoder is still being differentiated.  No per-step
+                   allocation, no copy-back.  Codebook gradients are covered too: they are linear in the
+                   per-code (count, sum) statistics.
     EMA statistics (count, sum) per level are all-reduced before the EMA update (improve fork).
     Sinkhorn level residual rows are all-gathered and every rank solves the global B x K problem
                    redundantly, keeping its slice: 1 collective instead of ~100 latency-bound ones.
-    BatchNorm      SyncBatchNorm (batch statistics over the global batch).
+    BatchNorm      statistics of the global batch (SyncBatchNorm semantics) by the library's own kernels with one
+                   all-reduce per layer and direction (layers._BatchNormAct).
     k-means init   rank 0 runs sklearn on the gathered first batch and broadcasts the centres.
+    NaN check      made on the all-reduced global loss, so every rank raises in the same step.
 
 Message sizes at the run.sh architecture: gradients 35 MB (768-d) / 90 MB (4096-d), bandwidth-bound
 -> left to RCCL's multi-ring over the 7 xGMI links; statistics <= 1.1 MB and the Sinkhorn gather
@@ -36,7 +43,8 @@ class DistContext:
 
     # ---- collectives (all no-ops when disabled)
     def reduce_gradients(self, model, n_local=None):
-        """Gradient of the global-batch mean loss from per-rank mean-loss gradients."""
+        """Gradient of the global-batch mean loss from per-rank mean-loss gradients: weighted all-reduce of whatever
+        .grad tensors exist, in place.  One-shot form (tests, callers without a GradReducer): packs into a temporary."""
         if not self.enabled:
             return
         params = [p for p in model.parameters() if p.grad is not None]
@@ -54,6 +62,29 @@ class DistContext:
             k = p.grad.numel()
             p.grad.copy_((flat[off:off + k] / total).view_as(p.grad))
             off += k
+
+    def set_batch(self, n_local, n_global):
+        """Rows of this rank / of all ranks in the current training batch (the loader knows both without a collective)."""
+        self.batch_rows = (int(n_local), int(n_global))
+
+    def merge_batch_stats(self, n_local, mean, m2):
+        """Per-rank BatchNorm statistics -> (mean, M2, n) of the global batch: every rank puts (n_r, mean_r, M2_r) into its
+        row of a [world, 2F+1] buffer, ONE all-reduce makes all rows visible everywhere, and the rows are merged by
+        mean = sum n_r mean_r / N,  M2 = sum (M2_r + n_r (mean_r - mean)^2) -- identical on every rank."""
+        F = mean.numel()
+        buf = torch.zeros((self.world_size, 2 * F + 1), dtype=torch.float32, device=mean.device)
+        row = buf[self.rank]
+        row[0] = float(n_local)
+        row[1:F + 1] = mean
+        row[F + 1:] = m2
+        tdist.all_reduce(buf, op=tdist.ReduceOp.SUM)
+        n = buf[:, :1]
+        rows = getattr(self, "batch_rows", None)
+        n_total = rows[1] if rows is not None and rows[0] == n_local else int(n.sum().item())
+        means, m2s = buf[:, 1:F + 1], buf[:, F + 1:]
+        g_mean = (n * means).sum(0) / float(n_total)
+        g_m2 = (m2s + n * (means - g_mean) ** 2).sum(0)
+        return g_mean, g_m2, n_total
 
     def _row_counts(self, n, device):
         counts = torch.zeros(self.world_size, dtype=torch.int64, device=device)
@@ -125,6 +156,68 @@ class DistContext:
             tdist.barrier()
 
 
+class GradReducer:
+    """Bucketed, overlapped gradient all-reduce over a persistent flat buffer.
+
+    Parameters' .grad become views of `flat`; `begin()` zeroes it (instead of optimizer.zero_grad, which would detach the
+    views); a post-accumulate hook on every parameter counts its bucket down and launches that bucket's all-reduce
+    (async) when the last gradient of the bucket has landed -- autograd produces them decoder-first, i.e. from the end
+    of the buffer towards its start; `finish()` waits for the outstanding buckets.  Ranks back-propagate a loss already
+    weighted by n_r / N, so the reduction is a plain SUM and nothing is rescaled afterwards."""
+
+    def __init__(self, ctx, params, bucket_bytes=8 << 20):
+        self.ctx = ctx
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets = []                        # [lo, hi) element ranges, in parameter order
+        self.bucket_of = {}
+        lo, members = 0, []
+        limit = max(1, bucket_bytes // 4)
+        for i, (p, off) in enumerate(zip(self.params, offs)):
+            members.append(p)
+            end = off + (p.numel() + 63) // 64 * 64
+            if end - lo >= limit or i == len(self.params) - 1:
+                for q in members:
+                    self.bucket_of[q] = len(self.buckets)
+                self.buckets.append((lo, end, len(members)))
+                lo, members = end, []
+        for p, off in zip(self.params, offs):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        self.launched = 0
+
+    def begin(self):
+        self.flat.zero_()
+        self._pending = [b[2] for b in self.buckets]
+        self._works = []
+
+    def _on_grad(self, p):
+        b = self.bucket_of.get(p)
+        if b is None or not self._pending:
+            return
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            lo, hi, _ = self.buckets[b]
+            self._works.append(tdist.all_reduce(self.flat[lo:hi], op=tdist.ReduceOp.SUM, async_op=True))
+            self.launched += 1
+
+    def finish(self):
+        for b, left in enumerate(self._pending):          # parameters that received no gradient this step: still reduce
+            if left > 0:
+                lo, hi, _ = self.buckets[b]
+                self._works.append(tdist.all_reduce(self.flat[lo:hi], op=tdist.ReduceOp.SUM, async_op=True))
+        for w in self._works:
+            w.wait()
+        self._works, self._pending = [], []
+
+
 _CTX = DistContext()
 
 
@@ -166,17 +259,25 @@ def init_from_env(args=None, backend=None):
 
 
 def attach(trainer, ctx):
-    """Make a Trainer data-parallel: SyncBatchNorm, identical initial weights, gradient all-reduce."""
+    """Make a Trainer data-parallel: identical initial weights, one checkpoint directory (rank 0's), and the bucketed
+    gradient all-reduce.  BatchNorm needs no module surgery: layers._BatchNormAct takes its statistics over the global
+    batch whenever a distributed context is active."""
     if not ctx.enabled:
         return trainer
     trainer.dist = ctx
     model = trainer.model
-    if getattr(model, "bn", False):
-        for part in ("encoder", "decoder"):
-            mlp = getattr(model, part)
-            mlp.mlp_layers = torch.nn.SyncBatchNorm.convert_sync_batchnorm(mlp.mlp_layers)
     for t in list(model.parameters()) + list(model.buffers()):
         tdist.broadcast(t.data, src=0)
+    # Trainer.__init__ made a time-stamped directory on every rank (trainer.py:37-38 names it by wall clock): keep rank 0's
+    names = [trainer.ckpt_dir]
+    tdist.broadcast_object_list(names, src=0)
+    if ctx.rank != 0 and names[0] != trainer.ckpt_dir:
+        try:
+            os.rmdir(trainer.ckpt_dir)
+        except OSError:
+            pass
+    trainer.ckpt_dir = names[0]
+    trainer.grad_reducer = GradReducer(ctx, list(model.parameters()))
     return trainer
 
 

@@ -146,7 +146,6 @@ class TrainEngine:
                 t = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=False)
                 y, mean, rstd = ops.bn_relu_forward(t, bn.weight.data, bn.bias.data, bn.eps, bn.momentum, bn.running_mean,
                                                     bn.running_var, relu=relu)
-                bn.num_batches_tracked.add_(1)
                 saved.append((h, lin, bn, relu, t, y, mean, rstd))
             else:
                 y = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=relu)
@@ -184,8 +183,11 @@ class TrainEngine:
         if eager and any(not q.initted for q in levels):
             m.rq._lazy_kmeans(z.reshape(-1, m.e_dim), True)                 # vq.py:67-68, first training batch only
         cbs = [q.embedding.weight.data for q in levels]
-        q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), True, True)
+        q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), True, True, want_code_grads=False)
         out, dec = self._mlp_forward(m.decoder, q["xq"])
+        counters = [s[2].num_batches_tracked for s in enc + dec if s[2] is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)                                 # BatchNorm1d.num_batches_tracked, all layers at once
         recon, g_out = ops.recon_loss_grad(out, x, m.loss_type)
         rq_loss = q["rq_loss"]
         loss = recon + m.quant_loss_weight * rq_loss                         # rqvae.py:83
@@ -193,8 +195,8 @@ class TrainEngine:
         g_loss = torch.full((), float(m.quant_loss_weight), dtype=torch.float32, device=x.device)
         gz = q["commit"] * g_loss
         gz = gz + g_xq                                                       # quantize._Quantize.backward, same order
-        for lvl, cg in zip(levels, q["code_grads"]):
-            torch.mul(cg, g_loss, out=self.grad_view[lvl.embedding.weight])
+        for lvl, cb, (cnt, tot) in zip(levels, cbs, q["stats"]):                 # (scale * (cnt*C - sum)) * g_loss, one launch per level
+            ops.codebook_grad(cnt, tot, cb, q["scale"], m.quant_loss_weight, self.grad_view[lvl.embedding.weight])
         self._mlp_backward(enc, gz, False)
         ops.grad_norm_clip(self.flat_g, self.max_norm, out=self.clip)
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.base_lr, self.betas, self.eps,

@@ -9,14 +9,66 @@ runs is different:
     GEMM epilogue), see csrc/gemm_f32.hip;
   * training       : the same kernel family for the forward GEMM and for both backward GEMMs
     (dX = dY W, dW = dY^T X; lcrec_linear_backward reads every operand as stored, no transposed
-    copies), batch-statistics BatchNorm through torch for now.
+    copies); batch-statistics BatchNorm (+ReLU) and its backward are one launch each
+    (lcrec_bn_relu_forward / _backward), global-batch statistics under data parallelism.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.init import xavier_normal_
 
+from . import dist as ldist
 from . import ops
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """y = [relu](BatchNorm1d(t)) in training mode (layers.py:25-30 of the reference) on the library's own kernels:
+    batch statistics, affine, ReLU and the running-statistics update in one launch, the backward (d t, d gamma, d beta)
+    in one more.  Under item-sharded data parallelism the batch is the union of all ranks' rows -- what
+    torch.nn.SyncBatchNorm computes -- with ONE all-reduce per direction: per-rank (n, mean, M2) rows merged in rank
+    order going forward, (sum g, sum g*xhat) going back; it needs nothing but all_reduce, so it also runs over gloo."""
+
+    @staticmethod
+    def forward(ctx, t, gamma, beta, bn, relu):
+        world = ldist.current()
+        n_local = t.shape[0]
+        if world.enabled:
+            mean_l, m2_l = ops.bn_stats(t)
+            mean, m2, n_total = world.merge_batch_stats(n_local, mean_l, m2_l)
+            rstd = torch.rsqrt(m2 / n_total + bn.eps)
+            y = ops.bn_relu_apply(t, gamma.detach(), beta.detach(), mean, rstd, relu)
+            with torch.no_grad():
+                mom = bn.momentum
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(m2 / max(n_total - 1, 1), alpha=mom)
+        else:
+            n_total = n_local
+            y, mean, rstd = ops.bn_relu_forward(t, gamma.detach(), beta.detach(), bn.eps, bn.momentum, bn.running_mean,
+                                                bn.running_var, relu=relu)
+        bn.num_batches_tracked += 1
+        ctx.relu, ctx.n_total, ctx.synced = relu, n_total, world.enabled
+        ctx.save_for_backward(t, y, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t, y, gamma, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.synced:
+            world = ldist.current()
+            local = ops.bn_backward_reduce(gy, t, y, mean, rstd, ctx.relu)
+            total = local.clone()
+            world.all_reduce_sum_(total)
+            dt, _ = ops.bn_backward_apply(gy, t, y, gamma.detach(), mean, rstd, total, ctx.n_total, ctx.relu)
+            return dt, local[1], local[0], None, None       # parameter gradients stay local: the gradient all-reduce sums them
+        dt, dgamma, dbeta, _ = ops.bn_relu_backward(gy, t, y, gamma.detach(), mean, rstd, ctx.relu)
+        return dt, dgamma, dbeta, None, None
+
+
+def _own_batchnorm(bn, x):
+    """Whether the library's BatchNorm kernels apply to this module call (else torch's own module runs)."""
+    return (type(bn) is nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and x.is_cuda and x.dim() == 2 and x.shape[0] >= 2 and torch.is_grad_enabled())
 
 
 class _LinearAct(torch.autograd.Function):
@@ -204,6 +256,9 @@ class MLPLayers(nn.Module):
                 bn = mods[g["bn"]]
                 if self.training:
                     x = _LinearAct.apply(x, lin.weight, lin.bias, False)
+                    if _own_batchnorm(bn, x) and (relu_mod is None or is_relu):
+                        x = _BatchNormAct.apply(x, bn.weight, bn.bias, bn, is_relu)     # batch statistics (+ ReLU), own kernels
+                        continue
                     x = bn(x)                      # batch statistics + running-stat update (torch)
                     if relu_mod is not None:
                         x = relu_mod(x)

@@ -534,6 +534,63 @@ def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, db
     return dt, dgamma, dbeta, dbias
 
 
+def bn_stats(t):
+    """(mean, m2) of this rank's rows: m2 = sum (t - mean)^2 (lcrec_bn_stats)."""
+    lib = _lib.load()
+    t = _dev(t, "t")
+    n, F = t.shape
+    mean = torch.empty(F, dtype=torch.float32, device=t.device)
+    m2 = torch.empty(F, dtype=torch.float32, device=t.device)
+    with _on(t.device):
+        rc = lib.lcrec_bn_stats(_ptr(t), n, F, _ptr(mean), _ptr(m2), _stream_ptr())
+    _lib.check(rc, "lcrec_bn_stats")
+    return mean, m2
+
+
+def bn_relu_apply(t, gamma, beta, mean, rstd, relu=True):
+    lib = _lib.load()
+    t = _dev(t, "t")
+    n, F = t.shape
+    y = torch.empty_like(t)
+    with _on(t.device):
+        rc = lib.lcrec_bn_relu_apply(_ptr(t), n, F, _ptr(_vec(gamma, "gamma", F)), _ptr(_vec(beta, "beta", F)),
+                                     _ptr(_vec(mean, "mean", F)), _ptr(_vec(rstd, "rstd", F)), int(bool(relu)), _ptr(y),
+                                     _stream_ptr())
+    _lib.check(rc, "lcrec_bn_relu_apply")
+    return y
+
+
+def bn_backward_reduce(gy, t, y, mean, rstd, relu=True):
+    """float32 [2, F]: (sum g, sum g * xhat) over this rank's rows (lcrec_bn_backward_reduce)."""
+    lib = _lib.load()
+    gy, t = _dev(gy, "gy"), _dev(t, "t")
+    n, F = t.shape
+    sums = torch.empty((2, F), dtype=torch.float32, device=t.device)
+    with _on(t.device):
+        rc = lib.lcrec_bn_backward_reduce(_ptr(gy), _ptr(t), _ptr(None if y is None else _dev(y, "y")), n, F,
+                                          _ptr(_vec(mean, "mean", F)), _ptr(_vec(rstd, "rstd", F)), int(bool(relu)),
+                                          _ptr(sums[0]), _ptr(sums[1]), _stream_ptr())
+    _lib.check(rc, "lcrec_bn_backward_reduce")
+    return sums
+
+
+def bn_backward_apply(gy, t, y, gamma, mean, rstd, sums, n_total, relu=True):
+    """(dt, dbias) from the all-reduced [2, F] sums (lcrec_bn_backward_apply)."""
+    lib = _lib.load()
+    gy, t = _dev(gy, "gy"), _dev(t, "t")
+    n, F = t.shape
+    sums = _dev(sums, "sums")
+    dt = torch.empty_like(t)
+    dbias = torch.empty(F, dtype=torch.float32, device=t.device)
+    with _on(t.device):
+        rc = lib.lcrec_bn_backward_apply(_ptr(gy), _ptr(t), _ptr(None if y is None else _dev(y, "y")), n, F,
+                                         _ptr(_vec(gamma, "gamma", F)), _ptr(_vec(mean, "mean", F)), _ptr(_vec(rstd, "rstd", F)),
+                                         int(bool(relu)), _ptr(sums[0]), _ptr(sums[1]), float(n_total), _ptr(dt), _ptr(dbias),
+                                         _stream_ptr())
+    _lib.check(rc, "lcrec_bn_backward_apply")
+    return dt, dbias
+
+
 def relu_bias_backward(gy, y, relu=True, dbias_out=None, inplace=False):
     """(g, dbias): g = gy * [y > 0] (or gy itself when relu is False), dbias = column sums of g."""
     lib = _lib.load()
@@ -577,6 +634,20 @@ def grad_norm_clip(flat_grads, max_norm=1.0, out=None):
         rc = lib.lcrec_grad_norm_clip(_ptr(g), g.numel(), float(max_norm), _ptr(res), _ptr(ws), ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_grad_norm_clip")
     return res
+
+
+def codebook_grad(count, total, codebook, scale, weight, out):
+    """out[k] = (scale * (count[k] * C[k] - sum[k])) * weight (see lcrec_codebook_grad); `out` is written in place."""
+    lib = _lib.load()
+    count, total, codebook = _dev(count, "count"), _dev(total, "sum"), _dev(codebook, "codebook")
+    K, e = codebook.shape
+    if not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (K, e)):
+        raise _lib.LcrecError("out must be a contiguous float32 [K, e] device tensor")
+    with _on(codebook.device):
+        rc = lib.lcrec_codebook_grad(_ptr(count), _ptr(total), _ptr(codebook), K, e, float(scale), float(weight), _ptr(out),
+                                     _stream_ptr())
+    _lib.check(rc, "lcrec_codebook_grad")
+    return out
 
 
 def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=True,

@@ -16,7 +16,7 @@ from . import dist as ldist
 from . import ops
 
 
-def quantize_values(zc, cbs, beta, plan, want_stats, training):
+def quantize_values(zc, cbs, beta, plan, want_stats, training, want_code_grads=True):
     """Values of the L-level quantiser on detached, contiguous inputs -- shared by the autograd node below and by the
     graph-captured training step (engine.py), which calls it without autograd.
     Returns dict(xq, rq_loss, idx, stats, resid_in, code_grads, commit); the last two (closed-form gradient factors, see
@@ -63,7 +63,9 @@ def quantize_values(zc, cbs, beta, plan, want_stats, training):
         stats = [ops.code_stats(idx[:, t], resid_in[t], cbs[t].shape[0]) for t in range(L)]
         scale = 2.0 / (L * n * e)
         out["stats"] = stats
-        out["code_grads"] = [scale * (cnt.unsqueeze(1) * cbs[t] - tot) for t, (cnt, tot) in enumerate(stats)]
+        out["scale"] = scale
+        if want_code_grads:
+            out["code_grads"] = [scale * (cnt.unsqueeze(1) * cbs[t] - tot) for t, (cnt, tot) in enumerate(stats)]
         out["commit"] = (beta * scale) * (zc - cbs[0].index_select(0, idx[:, 0]))
     return out
 

@@ -206,31 +206,46 @@ class Trainer(object):
                          disable=not self._is_main())
         params = list(self.model.parameters())          # one walk of the module tree per epoch, not per step
         # no host synchronisation inside a step: the launch queue stays a step ahead of the GPU
+        reducer = getattr(self, "grad_reducer", None) if self.dist is not None else None
         with ops.deferred_checks() as checks:
             for data in iter_data:
                 data = data.to(self.device)
-                self.optimizer.zero_grad()
+                if reducer is not None:
+                    n_local = data.shape[0]
+                    n_global = getattr(train_data, "last_global_rows", None)
+                    if n_global is None or self.dist.world_size == 1:
+                        n_global = self.dist.sum_int(n_local)
+                    self.dist.set_batch(n_local, n_global)
+                    reducer.begin()                   # zeroes the flat gradient buffer the .grad views live in
+                else:
+                    self.optimizer.zero_grad()
                 if self.use_ema:
                     out, rq_loss, _ = self.model(data, use_ema=True)
                 else:
                     out, rq_loss, _ = self.model(data)
                 loss, loss_recon = self.model.compute_loss(out, rq_loss, xs=data)
-                self._check_nan_async(loss)
-                loss.backward()
                 if self.dist is not None:
-                    self.dist.reduce_gradients(self.model, n_local=data.shape[0])
-                torch.nn.utils.clip_grad_norm_(params, 1.0)
-                self.optimizer.step()
-                self.scheduler.step()
-                # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step;
-                # data parallel: the loss of the global batch, not of this rank's slice
-                if self.dist is not None:
+                    # losses of the GLOBAL batch (what gets logged), and the NaN check on them: every rank sees the same
+                    # value, so every rank raises in the same step instead of leaving the others inside a collective
                     both = self.dist.global_means(torch.stack([loss.detach(), loss_recon.detach()]), data.shape[0])
+                    self._check_nan_async(both[0])
+                    if reducer is not None:
+                        (loss * (n_local / n_global)).backward()      # sum over ranks = gradient of the global mean loss
+                        reducer.finish()
+                    else:
+                        loss.backward()
+                        self.dist.reduce_gradients(self.model, n_local=data.shape[0])
                     total_loss += both[0]
                     total_recon += both[1]
                 else:
+                    self._check_nan_async(loss)
+                    loss.backward()
+                    # same values as `+= loss.item()` (fp32 -> double, summed in order) without a host sync per step
                     total_loss += loss.detach().double()
                     total_recon += loss_recon.detach().double()
+                torch.nn.utils.clip_grad_norm_(params, 1.0)
+                self.optimizer.step()
+                self.scheduler.step()
                 checks.poll()
             self._check_nan_drain()
         return total_loss.item(), total_recon.item()

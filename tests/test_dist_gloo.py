@@ -42,6 +42,34 @@ def _worker(rank, world, port, tmp):
     for p, q in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)
 
+    # ---- the training path's form of the same thing: persistent flat gradient buffer (.grad are views of it), buckets
+    # all-reduced from backward hooks as soon as their last gradient has landed, loss pre-weighted by n_r / N
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 40), torch.nn.ReLU(), torch.nn.Linear(40, 3))
+    ref2 = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 40), torch.nn.ReLU(), torch.nn.Linear(40, 3))
+    ref2.load_state_dict(net.state_dict())
+    torch.nn.functional.mse_loss(ref2(x), y).backward()
+    red = ldist.GradReducer(ctx, list(net.parameters()), bucket_bytes=4096)     # several buckets
+    assert len(red.buckets) >= 2 and all(p.grad.data_ptr() >= red.flat.data_ptr() for p in net.parameters())
+    for _ in range(2):                                                          # reusable step after step, no reallocation
+        ptr = red.flat.data_ptr()
+        red.begin()
+        (torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]) * ((hi - lo) / 11)).backward()
+        launched_in_backward = red.launched
+        red.finish()
+        assert red.flat.data_ptr() == ptr
+        for p, q in zip(net.parameters(), ref2.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)
+    assert launched_in_backward == 2 * len(red.buckets)                         # every bucket left from a hook, none from finish()
+
+    # ---- BatchNorm statistics of the global batch from per-rank (n, mean, M2): one all-reduce, same on every rank
+    t_all = torch.randn(11, 5, generator=torch.Generator().manual_seed(3)) * 3 + 7
+    mine_t = t_all[lo:hi]
+    ctx.set_batch(hi - lo, 11)
+    g_mean, g_m2, n_tot = ctx.merge_batch_stats(hi - lo, mine_t.mean(0), ((mine_t - mine_t.mean(0)) ** 2).sum(0))
+    assert n_tot == 11
+    assert torch.allclose(g_mean, t_all.mean(0), rtol=1e-6) and torch.allclose(g_m2, ((t_all - t_all.mean(0)) ** 2).sum(0), rtol=1e-5)
+
     # ---- logged losses are global-batch means
     means = ctx.global_means(torch.tensor([2.0 if rank == 0 else 4.0, 1.0]), n_local=hi - lo)
     assert torch.allclose(means, torch.tensor([(2.0 * 7 + 4.0 * 4) / 11, 1.0], dtype=torch.float64))

@@ -28,7 +28,7 @@ def trainer_probe(a):
         argv = ["--data_path", "unused", "--ckpt_dir", tmp, "--device", dev, "--batch_size", str(a.batch), "--epochs", "4",
                 "--no_kmeans_init", "--num_emb_list", "256", "256", "256", "256",          # run.sh: 4 levels, Sinkhorn on the last
                 "--sk_epsilons", "0.0", "0.0", "0.0", "0.0" if a.no_sk else "0.003"] \
-            + ([] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else []) + ["--train_engine", a.engine]
+            + (["--bn", "True"] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else []) + ["--train_engine", a.engine]
         args = cli.parse_args(argv)
         cli.seed_everything(2024)
         model = cli.build_model(args, a.in_dim)
