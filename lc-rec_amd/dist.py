@@ -92,11 +92,12 @@ class DistContext:
         tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
         return [int(c) for c in counts.tolist()]
 
-    def gather_rows(self, rows):
-        """Concatenate every rank's [n_r, ...] rows in rank order (n_r may differ)."""
+    def gather_rows(self, rows, counts=None):
+        """Concatenate every rank's [n_r, ...] rows in rank order (n_r may differ).  `counts`: the n_r of all ranks when
+        the caller already knows them (saves the all-reduce that would find them out)."""
         if not self.enabled:
             return rows
-        counts = self._row_counts(rows.shape[0], rows.device)
+        counts = [int(c) for c in counts] if counts is not None else self._row_counts(rows.shape[0], rows.device)
         width = max(counts)
         # gloo (the CPU rehearsal backend) has no all_gather for device tensors: stage through the host there
         via_host = rows.is_cuda and tdist.get_backend() == "gloo"

@@ -146,8 +146,14 @@ def assign_all(model, data, chunk_rows=1 << 20, audit=None):
 
 
 @torch.no_grad()
-def resolve_collisions(model, idx, resid_last, ks, max_rounds=MAX_ROUNDS, on_round=None):
-    """:101-128.  Mutates and returns idx; also returns the number of groups seen in each round."""
+def resolve_collisions(model, idx, resid_last, ks, max_rounds=MAX_ROUNDS, on_round=None, ctx=None):
+    """:101-128.  Mutates and returns idx; also returns the number of groups seen in each round.
+
+    With a distributed context (torchrun) a round's groups are SHARDED over the ranks: every
+    rank lists the groups (a device sort of the full index matrix, identical everywhere), solves a contiguous run of
+    them holding about 1/world of the colliding items, and one all-gather of the new last-level codes -- in rank order,
+    which is group order -- updates every rank's copy.  Groups are independent within a round, so the result is the
+    single-process one."""
     levels = list(model.rq.vq_layers)
     for q in levels[:-1]:
         q.sk_epsilon = 0.0
@@ -157,6 +163,7 @@ def resolve_collisions(model, idx, resid_last, ks, max_rounds=MAX_ROUNDS, on_rou
     cb_last = last.embedding.weight.detach().contiguous()
     L = len(levels)
     history = []
+    sharded = ctx is not None and ctx.enabled
     for _ in range(max_rounds):
         found = ops.collision_groups(idx, ks, want_groups="device")
         if found["n_groups"] == 0:
@@ -165,9 +172,25 @@ def resolve_collisions(model, idx, resid_last, ks, max_rounds=MAX_ROUNDS, on_rou
         if on_round is not None:
             on_round(len(history) - 1, found["n_groups"])
         members = found["members"]
-        rows = resid_last.index_select(0, members)
-        new_last = ops.sinkhorn_assign(rows, cb_last, last.sk_epsilon, last.sk_iters,
-                                       group_offsets=found["offsets"].cpu().numpy())
+        offs = found["offsets"].cpu().numpy()
+        if sharded and found["n_groups"] >= ctx.world_size:
+            # group boundaries nearest to equal shares of the colliding items
+            cuts = np.searchsorted(offs, [offs[-1] * r / ctx.world_size for r in range(1, ctx.world_size)], side="left")
+            bounds = np.concatenate([[0], np.minimum(cuts, found["n_groups"]), [found["n_groups"]]])
+            bounds = np.maximum.accumulate(bounds)
+            g_lo, g_hi = int(bounds[ctx.rank]), int(bounds[ctx.rank + 1])
+            mine = members[int(offs[g_lo]):int(offs[g_hi])]
+            if g_hi > g_lo:
+                rows = resid_last.index_select(0, mine)
+                new_mine = ops.sinkhorn_assign(rows, cb_last, last.sk_epsilon, last.sk_iters,
+                                               group_offsets=offs[g_lo:g_hi + 1] - offs[g_lo])
+            else:
+                new_mine = torch.zeros(0, dtype=torch.int64, device=idx.device)
+            counts = [int(offs[bounds[r + 1]] - offs[bounds[r]]) for r in range(ctx.world_size)]
+            new_last = ctx.gather_rows(new_mine, counts=counts)
+        else:
+            rows = resid_last.index_select(0, members)
+            new_last = ops.sinkhorn_assign(rows, cb_last, last.sk_epsilon, last.sk_iters, group_offsets=offs)
         idx[members, L - 1] = new_last
     return idx, history
 
@@ -239,8 +262,8 @@ def sharded_assign(ctx, data, assign_fn, device):
 def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True, ctx=None, trust_checkpoint=False):
     """Whole flow of generate_indices.py:51-145.  Returns a dict of the statistics it prints.
 
-    Under torchrun (ctx = dist.init_from_env()) pass 1 is item-sharded over the ranks; the conflict
-    rounds -- a few ms each, deterministic -- then run on every rank and rank 0 writes the file."""
+    Under torchrun (ctx = dist.init_from_env()) pass 1 is item-sharded over the ranks and each conflict round's
+    groups are sharded too (resolve_collisions); rank 0 writes the file."""
     from . import dist as ldist
     ctx = ctx or ldist.current()
     lead = ctx.rank == 0
@@ -264,7 +287,7 @@ def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=Tr
         if verbose:
             print(n_groups)
 
-    idx, history = resolve_collisions(model, idx, resid_last, ks, on_round=show)
+    idx, history = resolve_collisions(model, idx, resid_last, ks, on_round=show, ctx=ctx)
     _warn_if_reference_would_truncate(first_pass, idx)
     final = ops.collision_groups(idx, ks, want_groups=False)
     n = idx.shape[0]

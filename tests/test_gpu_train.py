@@ -217,7 +217,7 @@ def test_engine_equals_autograd_path_on_the_run_sh_architecture(hip, bn):
         if sa[k].dtype.is_floating_point:
             va, vb = sa[k].cpu().numpy(), sb[k].cpu().numpy()
             off = ~np.isclose(vb, va, rtol=1e-3, atol=5e-6)
-            assert off.sum() <= max(2, 0.01 * off.size) and np.abs(vb - va).max() < 2e-3, (k, off.sum(), np.abs(vb - va).max())
+            assert off.sum() <= max(4, 0.02 * off.size) and np.abs(vb - va).max() < 2e-3, (k, off.sum(), np.abs(vb - va).max())
         else:
             assert torch.equal(sa[k], sb[k]), k
 
