@@ -214,7 +214,7 @@ def test_engine_equals_autograd_path_on_the_run_sh_architecture(hip, bn):
     # Adam divides by sqrt(v): where a gradient entry is itself rounding noise (dead units) the update direction is too,
     # so a small fraction of entries may sit a fraction of one step (lr = 1e-3) apart; everything else agrees closely
     for k in sa:
-        if bn and k.startswith("encoder.") and sa[k].dtype.is_floating_point:
+        if bn and sa[k].dtype.is_floating_point:
             # With BatchNorm and these synthetic codebooks the gradient that reaches the encoder is what is left of
             # g - mean(g) - xhat * mean(g * xhat) after cancelling ~5 digits (tools/engine_diag.py: inputs of the last
             # encoder BatchNorm's backward agree to 2e-6 between the two paths, its output to 24 %; each output equals
