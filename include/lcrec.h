@@ -69,13 +69,15 @@ const char *lcrec_last_error(void);
  *     more than two library streams per device, whatever mix of calls it makes);
  *   - a ring of pinned host buffers through which lcrec_sinkhorn_assign uploads its group table without
  *     waiting on the host;
- *   - settings: the number of chunk pipelines of lcrec_encode_assign (1 or 2; default 2).
+ *   - settings: the number of chunk pipelines of lcrec_encode_assign (1 or 2; default 1).
  * Streams, events and pinned buffers are created on first use and released by lcrec_context_destroy,
  * which first waits for the helper streams to drain. */
 typedef struct lcrec_context lcrec_context;
 int lcrec_context_create(lcrec_context **out);
 int lcrec_context_destroy(lcrec_context *ctx);
-/* chunk pipelines of lcrec_encode_assign: 1 = every launch on the caller's stream, 2 (default) = see there. */
+/* chunk pipelines of lcrec_encode_assign: 1 (default) = every launch on the caller's stream; 2 = odd chunks on a helper
+ * stream: +1.5-1.9 % on C3 when the two streams' persistent GEMM launches share the CUs evenly, but the hardware dispatcher
+ * sometimes starves one of them (measured: a 61 ms pass taking 101 ms, round 1: 185 ms), so it is opt-in. */
 int lcrec_context_set_pipelines(lcrec_context *ctx, int pipelines);
 
 /* One MLP layer: y = [relu]( [bn]( x @ W^T + b ) ).
@@ -160,7 +162,7 @@ int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, co
  *   latent_out device [n][e] or NULL  encoder output
  *   others     as lcrec_rq_assign (margin_out / neartie_out / tie_tau: the near-tie audit of the quantiser)
  *   ctx        NULL, or a context of the current device
- * Items are processed in chunks of 131072.  With a context whose pipelines setting is 2, odd chunks run on
+ * Items are processed in chunks of 131072.  With a context whose pipelines setting is 2 (opt-in), odd chunks run on
  * the context's first helper stream, forked from `stream` by an event at entry and joined back into it before
  * the quantiser pass (and on every error exit), so everything is ordered after prior work on `stream` and
  * before later work on it, without any host synchronisation; with ctx == NULL or pipelines == 1 every launch

@@ -249,7 +249,9 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
     // context's first helper stream, forked from the caller's and joined back before the quantiser pass -- so two
     // layers' kernels are in flight at once and their workgroups interleave on the CUs: one kernel's store bursts,
     // prologues, narrow tail layers and last partial round run under the other's K loops.  Measured on C3: P = 2 is
-    // +1.7 % over P = 1, P = 3 and 4 give nothing.  The call still does not synchronise with the host.
+    // +1.5 .. +1.9 % over P = 1 in the common case, P = 3 and 4 give nothing -- but in a few percent of passes one stream's
+    // persistent launches are starved of CUs by the other's and the pass takes 1.6-3x (tools/generate_probe.py: wall 101 ms
+    // with 125 ms of kernel brackets against 61 / 120), so P = 1 is the default.  The call does not synchronise with the host.
     const int64_t n_chunks = (n + o.chunk - 1) / o.chunk;
     int P = ctx ? ctx->pipelines : 1;
     if (P > ENC_PIPES_MAX) P = ENC_PIPES_MAX;

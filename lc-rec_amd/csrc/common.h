@@ -53,7 +53,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct lcrec_context {
     static constexpr int HELPERS = 2, RING = 4;
     int device = 0;
-    int pipelines = 2;
+    int pipelines = 1;
     bool streams_ready = false;
     hipStream_t helper[HELPERS] = {};
     hipEvent_t fork = nullptr, join[HELPERS] = {};

@@ -89,7 +89,7 @@ def release_workspaces():
 # One lcrec_context per device (include/lcrec.h): the library's helper streams, their events and the pinned upload ring.
 # Created on first use by the two calls that can overlap launches, destroyed at interpreter exit / release_contexts().
 _contexts = {}
-_pipelines = 2
+_pipelines = 1
 
 
 def _context(device):
@@ -105,7 +105,8 @@ def _context(device):
 
 
 def set_pipelines(n):
-    """Chunk pipelines of encode_assign (lcrec_context_set_pipelines): 1 = everything on the current stream, 2 = default."""
+    """Chunk pipelines of encode_assign (lcrec_context_set_pipelines): 1 (default) = everything on the current stream,
+    2 = odd chunks on a helper stream (+1.5-1.9 % on C3, but see include/lcrec.h: intermittently much slower)."""
     global _pipelines
     n = int(n)
     if n not in (1, 2):
