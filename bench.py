@@ -272,18 +272,31 @@ def main():
 
     # Algorithmic flops per GEMM kernel: replay the library's dispatch rule (gemm_f32.hip, linear_forward)
     # over the chunks lcrec_encode_assign walks (131072 rows each).
-    def gemm_kernel_for(rows, out, k):
+    def gemm_pieces(rows, out, k):
+        """[(kernel name, rows)] of one Linear launch: the library's dispatch rule (gemm_f32.hip, linear_forward)."""
         if out <= 32:
-            return "linear_fwd_128x32"
+            return [("linear_fwd_128x32", rows)]
         if out <= 64:
-            return "linear_fwd_128x64"
-        pp_tiles = -(-rows // 256) * -(-out // 128)
+            return [("linear_fwd_128x64", rows)]
+        ntile = -(-out // 128)
+        pp_tiles = -(-rows // 256) * ntile
         rounds = -(-pp_tiles // 256)
         fits = pp_tiles >= 256 and (rounds >= 8 or pp_tiles * 5 >= rounds * 256 * 4)
         forced = os.environ.get("LCREC_GEMM_PP", "-1")
+        last0 = pp_tiles % 256
+        if k % 32 == 0 and forced == "-1" and rounds < 8 and last0 != 0 and last0 * 10 < 256 * 9:
+            # mid-sized launch with a mostly empty last round: whole rounds to the ping-pong kernel, the tail apart
+            p = rows // 256
+            while p >= 1 and p * ntile >= 256 and p >= rows // 256 - 256 // ntile:
+                last = (p * ntile) % 256
+                if last == 0 or last * 10 >= 256 * 9:
+                    if p * 256 >= rows:
+                        break
+                    return [("linear_fwd_pp_256x128", p * 256)] + gemm_pieces(rows - p * 256, out, k)
+                p -= 1
         if k % 32 == 0 and (forced == "1" or (forced != "0" and fits)):
-            return "linear_fwd_pp_256x128"
-        return "linear_fwd_64x64" if -(-rows // 128) * -(-out // 128) < 512 else "linear_fwd_128x128"
+            return [("linear_fwd_pp_256x128", rows)]
+        return [("linear_fwd_64x64" if -(-rows // 128) * ntile < 512 else "linear_fwd_128x128", rows)]
 
     macs_all = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1)) + sum(E_DIM * k for k in ks)
     flops, alg_bytes = {}, {}
@@ -291,10 +304,10 @@ def main():
         rows = min(131072, n - lo)
         for l in range(len(dims) - 1):
             out = dims[l + 1]
-            kname = gemm_kernel_for(rows, out, dims[l])
-            flops[kname] = flops.get(kname, 0.0) + 2.0 * rows * dims[l] * out * args.steps
-            # read the activations and the weights once, write the outputs once
-            alg_bytes[kname] = alg_bytes.get(kname, 0.0) + 4.0 * (rows * dims[l] + out * dims[l] + rows * out) * args.steps
+            for kname, part in gemm_pieces(rows, out, dims[l]):
+                flops[kname] = flops.get(kname, 0.0) + 2.0 * part * dims[l] * out * args.steps
+                # read the activations and the weights once, write the outputs once
+                alg_bytes[kname] = alg_bytes.get(kname, 0.0) + 4.0 * (part * dims[l] + out * dims[l] + part * out) * args.steps
     dom = max(flops, key=lambda k: flops[k])
 
     def kernel_rate(tr, steps):

@@ -1217,6 +1217,27 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     const int64_t pp_rounds = (pp_tiles + 255) / 256;
     const bool pp_fits = pp_tiles >= 256 && (pp_rounds >= 8 || pp_tiles * 5 >= pp_rounds * 256 * 4);
     const bool pp_ok = in_dim % BK == 0 && (int64_t)in_dim * 4 * 192 < (1ll << 31);     // else the generic kernels
+    // Mid-sized launches (Games: 16 859 rows = 65.9 row panels) leave the last round of 256 x 128 tiles mostly empty --
+    // 1056 tiles are 4.1 rounds, 528 are 2.06 -- and a persistent workgroup's time is its LONGEST tile list.  Rows are
+    // independent, so such a launch is cut at a row-panel boundary: the largest head whose tiles fill whole rounds (or
+    // >= 90 % of the last one) goes to the ping-pong kernel, the tail (here 475 rows) to the generic kernels in a second
+    // launch.  Same chains, same bits.  Launches of >= 8 rounds are left alone (their partial round is noise).
+    const int64_t pp_last = pp_tiles % 256;
+    if (out_dim > 64 && pp_ok && pp == -1 && pp_rounds < 8 && pp_last != 0 && pp_last * 10 < 256 * 9) {
+        const int64_t ntile = (out_dim + 127) / 128;
+        // (the tail stays below one round of tiles: look back at most 256 / ntile panels)
+        for (int64_t p = n / 256; p >= 1 && p * ntile >= 256 && p >= n / 256 - 256 / ntile; --p) {
+            const int64_t t = p * ntile, last = t % 256;
+            if (last == 0 || last * 10 >= 256 * 9) {
+                const int64_t head = p * 256;
+                if (head >= n) break;                     // the whole launch is already whole rounds
+                int rc = launch_linear_pp(x, head, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
+                if (rc) return rc;
+                return linear_forward(x + head * in_dim, n - head, in_dim, W, b, bn_scale, bn_shift, relu, out_dim,
+                                      y + head * out_dim, stream);
+            }
+        }
+    }
     const bool use_pp = out_dim > 64 && pp_ok && (pp == 1 || (pp == -1 && pp_fits));
     if (use_pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
     if (out_dim > 64) {
