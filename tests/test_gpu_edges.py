@@ -138,3 +138,49 @@ def test_collision_groups_property_random_shapes(hip):
         dev = hip.ops.collision_groups(torch.from_numpy(rows).to("cuda:0"), Ks, want_groups="device")
         offs, mem = dev["offsets"].tolist(), dev["members"].tolist()
         assert [mem[offs[g]:offs[g + 1]] for g in range(dev["n_groups"])] == want
+
+
+def test_context_pipelines_and_lifetime(hip):
+    """lcrec_context (include/lcrec.h): the second chunk pipeline and the Sinkhorn size classes on helper streams change
+    scheduling, never results; contexts can be destroyed and re-created; NULL context = every launch on the caller's stream."""
+    import ctypes
+    from lcrec_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    dims = [256, 512, 128, 32]
+    Ws = [torch.randn((dims[l + 1], dims[l]), generator=g, device=dev) * 0.05 for l in range(3)]
+    bs = [0.01 * torch.randn(dims[l + 1], generator=g, device=dev) for l in range(3)]
+    cbs = [torch.randn((64, 32), generator=g, device=dev) * 0.5 ** l for l in range(3)]
+    flat, ks = ops.flatten_codebooks(cbs)
+    x = torch.randn((400_000, 256), generator=g, device=dev)               # 4 chunks of 131 072: both pipelines get work
+    try:
+        ops.set_pipelines(1)
+        one = ops.encode_assign(x, Ws, bs, flat, ks, want_latent=True)
+        ops.set_pipelines(2)
+        two = ops.encode_assign(x, Ws, bs, flat, ks, want_latent=True)
+        assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1])
+        ops.release_contexts()                                              # drains and destroys the helper streams ...
+        again = ops.encode_assign(x, Ws, bs, flat, ks, want_latent=True)    # ... and the next call makes a new context
+        assert torch.equal(again[0], one[0])
+    finally:
+        ops.set_pipelines(1)
+    # Sinkhorn over many groups: with the context (helper streams + pinned ring) == with NULL (one stream, host wait)
+    lib = hip._lib.load()
+    rs = np.random.RandomState(5)
+    sizes = list(rs.randint(2, 40, size=300)) + [70, 300, 900] + [120] * 20
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    r = torch.randn((n, 32), generator=g, device=dev)
+    cb = torch.randn((256, 32), generator=g, device=dev)
+    with_ctx = ops.sinkhorn_assign(r, cb, 0.003, 50, group_offsets=offs)
+    out = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    oarr = offs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    nbytes = lib.lcrec_sinkhorn_assign_workspace(n, 256, oarr, len(sizes))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = lib.lcrec_sinkhorn_assign(r.data_ptr(), n, 32, cb.data_ptr(), 256, oarr, len(sizes), 0.003, 50, out.data_ptr(), 1,
+                                   ws.data_ptr(), nbytes, None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and torch.equal(out, with_ctx)
+    h = ctypes.c_void_p()
+    assert lib.lcrec_context_create(ctypes.byref(h)) == 0 and h.value
+    assert lib.lcrec_context_set_pipelines(h, 3) == -1 and b"supported" in lib.lcrec_last_error()
+    assert lib.lcrec_context_destroy(h) == 0
