@@ -27,7 +27,9 @@ into them.
 Measured and dropped: weight gradients (leaves of the dependency graph) and the per-code statistics on a second stream,
 i.e. parallel branches in the captured graph, so that the narrow layers' GEMMs run beside the dX chain: 26 fork/join
 pairs per step cost more than the overlap gains at batch 1024 (1.80 -> 1.88 ms/step, bn=True 1.99 -> 2.08) and barely pay
-at 2048 (2.51 -> 2.45).
+at 2048 (2.51 -> 2.45).  With ONE fork/join (the decoder's seven weight gradients queued and run beside the encoder's
+chain) nothing changes at 1024 (1.80 -> 1.82) and little at 2048 (2.51 -> 2.46): the replayed graph does not run the two
+branches' under-filled kernels side by side to any useful degree.
 
 What the engine does not cover falls back to the autograd path in trainer.py, unchanged: data-parallel runs, the EMA
 codebook update of index_improve/, dropout > 0, activations other than ReLU, optimisers other than Adam/AdamW,
