@@ -113,6 +113,22 @@ size_t lcrec_linear_backward_workspace(int64_t n, int in_dim, int out_dim);
 int lcrec_linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim,
                           float *gx_out, float *gw_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The weight gradients of SEVERAL Linear layers in one launch: gw_p = gy_p^T * x_p for p < count (count <= 16), each
+ * exactly what lcrec_linear_backward computes for that layer -- the same S = lcrec_linear_backward_splits runs, added in
+ * order -- so the results are bit-identical to per-layer calls.  A training step's narrow layers are a handful of tiles
+ * each; launched together their workgroups fill the chip (index/trainer.py:117: autograd produces these one at a time).
+ * `problems` is a HOST array; all pointers inside are device pointers.  Widths must be multiples of 4. */
+typedef struct {
+    const float *gy;   /* [n][out_dim] gradient w.r.t. the layer's pre-activation output */
+    const float *x;    /* [n][in_dim]  the layer's input */
+    float *gw;         /* [out_dim][in_dim] */
+    int64_t n;
+    int in_dim, out_dim;
+} lcrec_dw_problem;
+size_t lcrec_linear_backward_weights_workspace(const lcrec_dw_problem *problems, int count);
+int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, int count, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
 /* L-level residual quantisation with hard (argmin) assignment.
  * Replaces ResidualVectorQuantizer.forward, index/models/rq.py:39-55, over
  * VectorQuantizer.forward with use_sk=False, index/models/vq.py:63-99

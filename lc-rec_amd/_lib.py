@@ -29,6 +29,8 @@ _SIGNATURES = {
     "lcrec_linear_backward_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "lcrec_linear_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
                                              ctypes.c_size_t, _vp]),
+    "lcrec_linear_backward_weights_workspace": (ctypes.c_size_t, [_vp, ctypes.c_int]),
+    "lcrec_linear_backward_weights": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "lcrec_rq_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                     ctypes.c_int]),
     "lcrec_context_create": (ctypes.c_int, [ctypes.POINTER(_vp)]),
@@ -80,6 +82,12 @@ _SIGNATURES = {
     "lcrec_trace_enable": (ctypes.c_int, [ctypes.c_int]),
     "lcrec_trace_collect": (ctypes.c_int, [_vp, ctypes.c_int]),
 }
+
+
+class DwProblem(ctypes.Structure):
+    """lcrec_dw_problem of include/lcrec.h"""
+    _fields_ = [("gy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("gw", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int)]
 
 
 class TraceEntry(ctypes.Structure):

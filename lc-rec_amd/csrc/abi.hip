@@ -444,3 +444,15 @@ LCREC_API int lcrec_bn_backward_apply(const float *gy, const float *t, const flo
     return bn_backward_apply(gy, t, y, n, features, gamma, mean, rstd, relu, sum_g, sum_gx, n_total, dt_out, dbias_out,
                              (hipStream_t)stream);
 }
+
+LCREC_API size_t lcrec_linear_backward_weights_workspace(const lcrec_dw_problem *problems, int count)
+{
+    if (!problems || count < 1) return 0;
+    return linear_backward_weights_workspace(problems, count);
+}
+
+LCREC_API int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, int count, void *workspace, size_t workspace_bytes,
+                                            void *stream)
+{
+    return linear_backward_weights(problems, count, workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -110,6 +110,9 @@ size_t linear_backward_workspace(int64_t n, int in_dim, int out_dim);
 int linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim, float *gx, float *gw,
                     void *workspace, size_t workspace_bytes, hipStream_t stream);
 
+size_t linear_backward_weights_workspace(const lcrec_dw_problem *problems, int count);
+int linear_backward_weights(const lcrec_dw_problem *problems, int count, void *workspace, size_t workspace_bytes, hipStream_t stream);
+
 size_t rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
               int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,

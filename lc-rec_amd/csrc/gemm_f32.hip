@@ -195,11 +195,14 @@ __device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t r, int
 // k-major "W" of an [n][in] output, dW = dY^T X reads dY [n][out] and X [n][in] both k-major -- so no transposed
 // copy of W, dY or X is ever made.  The transposition happens in the LDS write (ds_write2_b32 places the four
 // rows of a 16-byte global load); chain order over k is unchanged.  Requires FAST.
+// The tile body; `bid` / `split` are the workgroup's tile number and K-run (blockIdx.x / blockIdx.y of a plain launch, or
+// what a grouped launch derives from its problem table).
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, bool TB = false>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(
+__device__ __forceinline__ void linear_tile_body(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
-    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune, int kt_per_split, int64_t split_stride)
+    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune, int kt_per_split, int64_t split_stride,
+    unsigned bid, unsigned split)
 {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -216,14 +219,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     int64_t bm;
     int bn;
     if (tune & 1) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xcd = bid & 7, j = bid >> 3;
         const int panels = (bm_blocks - xcd + 7) >> 3;
         if (j >= panels * bn_blocks) return;
         bm = (int64_t)(j / bn_blocks) * 8 + xcd;
         bn = j % bn_blocks;
     } else {
-        bm = blockIdx.x / bn_blocks;
-        bn = blockIdx.x % bn_blocks;
+        bm = bid / bn_blocks;
+        bn = bid % bn_blocks;
     }
     const int64_t m0 = bm * BM;
     const int n0 = bn * BN;
@@ -248,9 +251,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     // K-tiles [kt0, nk) of its split and writes a partial result at C + blockIdx.y * split_stride; a second kernel adds
     // the partials in split order.  Forward launches pass kt_per_split = all K-tiles, gridDim.y = 1.
     const int nk_all = (K + BK - 1) / BK;
-    const int kt0 = blockIdx.y * kt_per_split;
+    const int kt0 = split * kt_per_split;
     const int nk = kt0 + kt_per_split < nk_all ? kt0 + kt_per_split : nk_all;
-    C += blockIdx.y * split_stride;
+    C += split * split_stride;
 
     static_assert(FAST || (!TA && !TB), "k-major operands need the buffer-load path");
     // FAST (K % 32 == 0): buffer loads + ds_write2_b32 -- no VALU in the staging path; thread p of a pass covers
@@ -379,6 +382,64 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
         for (int i = 0; i < TM; ++i)
             store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * TM * 32 + i * 32, M, n0 + wn * TN * 32 + j * 32, N, bias,
                              bn_scale, bn_shift, relu);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, bool TB = false>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
+    int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune, int kt_per_split, int64_t split_stride)
+{
+    linear_tile_body<WAVES_M, WAVES_N, TM, TN, FAST, TA, TB>(A, W, bias, bn_scale, bn_shift, C, M, N, K, relu, bn_blocks, bm_blocks,
+                                                             tune, kt_per_split, split_stride, blockIdx.x, blockIdx.y);
+}
+
+// Several independent weight-gradient products dW_p = dY_p^T X_p in ONE launch (64 x 64 tiles, both operands k-major):
+// the narrow layers of a training step are a handful of tiles each and leave most CUs idle when launched one by one;
+// side by side their workgroups fill the chip.  Workgroup w belongs to the problem whose [wg_start, wg_start + wgs)
+// range holds it; inside a problem, w - wg_start = split * tiles + tile.
+constexpr int DW_GROUP_MAX = 16;
+struct DwGroup {
+    int count;
+    const float *A[DW_GROUP_MAX], *B[DW_GROUP_MAX];
+    float *C[DW_GROUP_MAX];                      // partial buffer when splits > 1, else the gradient itself
+    int M[DW_GROUP_MAX], N[DW_GROUP_MAX], K[DW_GROUP_MAX];
+    int bn_blocks[DW_GROUP_MAX], bm_blocks[DW_GROUP_MAX], tiles[DW_GROUP_MAX], kt_per_split[DW_GROUP_MAX];
+    unsigned wg_start[DW_GROUP_MAX + 1];
+};
+
+__global__ __launch_bounds__(256) void linear_dw_grouped_kernel(DwGroup g)
+{
+    int p = 0;
+#pragma unroll 1
+    while (p + 1 < g.count && blockIdx.x >= g.wg_start[p + 1]) ++p;
+    const unsigned local = blockIdx.x - g.wg_start[p];
+    const unsigned tile = local % (unsigned)g.tiles[p], split = local / (unsigned)g.tiles[p];
+    linear_tile_body<2, 2, 1, 1, true, true, true>(g.A[p], g.B[p], nullptr, nullptr, nullptr, g.C[p], g.M[p], g.N[p], g.K[p], 0,
+                                                   g.bn_blocks[p], g.bm_blocks[p], 1, g.kt_per_split[p],
+                                                   (int64_t)g.M[p] * g.N[p], tile, split);
+}
+
+struct DwReduce {
+    int count;
+    const float *partial[DW_GROUP_MAX];
+    float *out[DW_GROUP_MAX];
+    int splits[DW_GROUP_MAX];
+    unsigned total4[DW_GROUP_MAX], wg_start[DW_GROUP_MAX + 1];
+};
+
+// gw_p = ((p0 + p1) + p2) + ... for every problem with more than one K-run, one launch
+__global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(DwReduce r)
+{
+    int p = 0;
+#pragma unroll 1
+    while (p + 1 < r.count && blockIdx.x >= r.wg_start[p + 1]) ++p;
+    const unsigned q = (blockIdx.x - r.wg_start[p]) * 256u + threadIdx.x;
+    if (q >= r.total4[p]) return;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(r.partial[p]);
+    f32x4 acc = src[q];
+    for (int s2 = 1; s2 < r.splits[p]; ++s2) acc = acc + src[(size_t)s2 * r.total4[p] + q];
+    reinterpret_cast<f32x4 *>(r.out[p])[q] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1191,6 +1252,71 @@ int linear_backward(const float *gy, const float *x, const float *W, int64_t n, 
         if (rc) return rc;
     }
     return LCREC_OK;
+}
+
+// ---- grouped weight gradients (lcrec_linear_backward_weights): same S and run lengths per problem as linear_backward,
+// hence the same bits; one launch for the products, one for the ordered sums of their K-runs
+size_t linear_backward_weights_workspace(const lcrec_dw_problem *pr, int count)
+{
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) total += align_up(linear_backward_workspace(pr[i].n, pr[i].in_dim, pr[i].out_dim), 256);
+    return total;
+}
+
+int linear_backward_weights(const lcrec_dw_problem *pr, int count, void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    if (count == 0) return LCREC_OK;
+    if (!pr || count < 0 || count > DW_GROUP_MAX)
+        return fail(LCREC_EINVAL, "linear_backward_weights: %d problems (1..%d supported)", count, DW_GROUP_MAX);
+    if (workspace_bytes < linear_backward_weights_workspace(pr, count) || (!workspace && linear_backward_weights_workspace(pr, count)))
+        return fail(LCREC_EWORKSPACE, "linear_backward_weights: workspace %zu B < required %zu B", workspace_bytes,
+                    linear_backward_weights_workspace(pr, count));
+    DwGroup g = {};
+    DwReduce r = {};
+    char *ws = reinterpret_cast<char *>(workspace);
+    unsigned wg = 0, rwg = 0;
+    for (int i = 0; i < count; ++i) {
+        const lcrec_dw_problem &q = pr[i];
+        if (!q.gy || !q.x || !q.gw) return fail(LCREC_EINVAL, "linear_backward_weights: NULL pointer in problem %d", i);
+        if (q.n <= 0 || q.in_dim <= 0 || q.out_dim <= 0 || q.in_dim % 4 || q.out_dim % 4)
+            return fail(LCREC_EUNSUPPORTED, "linear_backward_weights: problem %d: n=%lld in=%d out=%d (positive, widths multiples of 4)", i,
+                        (long long)q.n, q.in_dim, q.out_dim);
+        if (((uintptr_t)q.gy | (uintptr_t)q.x | (uintptr_t)q.gw) & 15)
+            return fail(LCREC_EINVAL, "linear_backward_weights: operands must be 16-byte aligned");
+        const int64_t widest = q.in_dim > q.out_dim ? q.in_dim : q.out_dim;
+        if ((q.n + 64) * widest * 4 >= (1ll << 31) || (int64_t)q.out_dim * q.in_dim * 4 >= (1ll << 31))
+            return fail(LCREC_EUNSUPPORTED, "linear_backward_weights: problem %d exceeds the 2 GiB a buffer descriptor spans", i);
+        const int splits = linear_backward_splits(q.n, q.in_dim, q.out_dim);
+        const int nk = (int)((q.n + BK - 1) / BK);
+        const int64_t bm_blocks = (q.out_dim + 63) / 64;
+        const int bn_blocks = (q.in_dim + 63) / 64;
+        const int64_t tiles = ((bm_blocks + 7) / 8) * 8 * bn_blocks;      // XCD-aware numbering has holes (see linear_tile_body)
+        g.A[i] = q.gy; g.B[i] = q.x;
+        g.M[i] = q.out_dim; g.N[i] = q.in_dim; g.K[i] = (int)q.n;
+        g.bn_blocks[i] = bn_blocks; g.bm_blocks[i] = (int)bm_blocks; g.tiles[i] = (int)tiles;
+        g.kt_per_split[i] = splits > 1 ? (nk + splits - 1) / splits : 1 << 30;
+        g.wg_start[i] = wg;
+        wg += (unsigned)(tiles * (splits > 1 ? splits : 1));
+        if (splits > 1) {
+            float *partial = reinterpret_cast<float *>(ws);
+            ws += align_up(linear_backward_workspace(q.n, q.in_dim, q.out_dim), 256);
+            g.C[i] = partial;
+            const int j = r.count++;
+            r.partial[j] = partial; r.out[j] = q.gw; r.splits[j] = splits;
+            r.total4[j] = (unsigned)((int64_t)q.out_dim * q.in_dim / 4);
+            r.wg_start[j] = rwg;
+            rwg += (r.total4[j] + 255) / 256;
+        } else {
+            g.C[i] = q.gw;
+        }
+    }
+    g.count = count;
+    g.wg_start[count] = wg;
+    r.wg_start[r.count] = rwg;
+    TraceScope trace(K_LINEAR_64x64, stream);
+    hipLaunchKernelGGL(linear_dw_grouped_kernel, dim3(wg), dim3(256), 0, stream, g);
+    if (r.count) hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3(rwg), dim3(256), 0, stream, r);
+    return check_launch("linear_dw_grouped_kernel");
 }
 
 int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const float *b,

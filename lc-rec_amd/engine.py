@@ -13,8 +13,9 @@ the same lcrec_* entry points the module API uses, so forward values and GEMM gr
     decoder  same
     loss     mse|l1 + quant_loss_weight * rq_loss, and d loss / d out   lcrec_recon_loss_grad
     backward decoder, closed-form quantiser gradients, encoder         lcrec_bn_relu_backward / lcrec_relu_bias_backward,
-                                                                       lcrec_linear_backward (dW written straight into the
-                                                                       flat gradient buffer)
+                                                                       lcrec_linear_backward (dX), and ONE grouped launch
+                                                                       for all weight gradients, written straight into the
+                                                                       flat gradient buffer (lcrec_linear_backward_weights)
     clip 1.0 + AdamW + warm-up schedule                                lcrec_grad_norm_clip, lcrec_adamw_step (learning
                                                                        rate and bias corrections from a device step counter)
     loss sums, NaN flag                                                device accumulators, read once per epoch
@@ -160,7 +161,10 @@ class TrainEngine:
             h = y
         return h, saved
 
-    def _mlp_backward(self, saved, g, need_input_grad):
+    def _mlp_backward(self, saved, g, need_input_grad, dw):
+        """The dX chain of one MLP: BatchNorm/ReLU backward -> dX GEMM -> next layer.  Weight gradients are leaves of the
+        dependency graph and most of them are a handful of tiles: they are queued in `dw` as (dt, layer input, gradient
+        view) and computed by ONE grouped launch at the end of the step (lcrec_linear_backward_weights)."""
         gv = self.grad_view
         for i in range(len(saved) - 1, -1, -1):
             h, lin, bn, relu, t, y, mean, rstd = saved[i]
@@ -169,18 +173,17 @@ class TrainEngine:
                                                    dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias])
             else:
                 dt, _ = ops.relu_bias_backward(g, y, relu, dbias_out=gv[lin.bias], inplace=True)
-            need_gx = i > 0 or need_input_grad
-            w = lin.weight.data
-            out_dim = w.shape[0]
-            pad = (-out_dim) % 32                       # layers._LinearAct.backward: K slice of the k-major kernels
-            if pad:
-                dt = torch.nn.functional.pad(dt, (0, pad))
-                w = torch.nn.functional.pad(w, (0, 0, 0, pad))
-                gx, gw = ops.linear_backward(dt, h, w, need_gx, True)
-                gv[lin.weight].copy_(gw[:out_dim])
+            dw.append((dt, h, gv[lin.weight]))
+            if i > 0 or need_input_grad:
+                w = lin.weight.data
+                pad = (-w.shape[0]) % 32                # layers._LinearAct.backward: K slice of the k-major dX kernel
+                if pad:
+                    g = ops.linear_backward(torch.nn.functional.pad(dt, (0, pad)), h, torch.nn.functional.pad(w, (0, 0, 0, pad)),
+                                            True, False)[0]
+                else:
+                    g = ops.linear_backward(dt, h, w, True, False)[0]
             else:
-                gx, _ = ops.linear_backward(dt, h, w, need_gx, True, gw_out=gv[lin.weight])
-            g = gx
+                g = None
         return g
 
     def _run(self, x, eager):
@@ -198,13 +201,16 @@ class TrainEngine:
         recon, g_out = ops.recon_loss_grad(out, x, m.loss_type)
         rq_loss = q["rq_loss"]
         loss = recon + m.quant_loss_weight * rq_loss                         # rqvae.py:83
-        g_xq = self._mlp_backward(dec, g_out, True)
+        dw = []
+        g_xq = self._mlp_backward(dec, g_out, True, dw)
         g_loss = torch.full((), float(m.quant_loss_weight), dtype=torch.float32, device=x.device)
         gz = q["commit"] * g_loss
         gz = gz + g_xq                                                       # quantize._Quantize.backward, same order
         for lvl, cb, (cnt, tot) in zip(levels, cbs, q["stats"]):                 # (scale * (cnt*C - sum)) * g_loss, one launch per level
             ops.codebook_grad(cnt, tot, cb, q["scale"], m.quant_loss_weight, self.grad_view[lvl.embedding.weight])
-        self._mlp_backward(enc, gz, False)
+        self._mlp_backward(enc, gz, False, dw)
+        ops.linear_backward_weights(dw)                                      # all 14 weight gradients, one launch
+        del dw
         ops.grad_norm_clip(self.flat_g, self.max_norm, out=self.clip)
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.base_lr, self.betas, self.eps,
                        self.weight_decay, self.decoupled, clip=self.clip, schedule=self.schedule,

@@ -190,6 +190,32 @@ def linear_backward(gy, x, weight, need_gx=True, need_gw=True, gw_out=None):
     return gx, gw
 
 
+def linear_backward_weights(problems):
+    """Weight gradients of several Linear layers in ONE launch (lcrec_linear_backward_weights): `problems` is a list of
+    (gy [n, out], x [n, in], gw_out [out, in]) device tensors; every gw_out is written in place, bit-identical to what
+    linear_backward(gy, x, W, need_gx=False) computes for that layer."""
+    lib = _lib.load()
+    count = len(problems)
+    if count == 0:
+        return
+    arr = (_lib.DwProblem * count)()
+    keep = []
+    for i, (gy, x, gw) in enumerate(problems):
+        gy, x = _dev(gy, "gy"), _dev(x, "x")
+        n, out_dim = gy.shape
+        in_dim = x.shape[1]
+        if x.shape[0] != n or tuple(gw.shape) != (out_dim, in_dim) or not gw.is_contiguous() or gw.dtype != torch.float32:
+            raise _lib.LcrecError(f"linear_backward_weights: problem {i}: gy {tuple(gy.shape)}, x {tuple(x.shape)}, gw {tuple(gw.shape)}")
+        arr[i] = _lib.DwProblem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), n, in_dim, out_dim)
+        keep += [gy, x]
+    dev = problems[0][0].device
+    with _on(dev):
+        nbytes = lib.lcrec_linear_backward_weights_workspace(ctypes.cast(arr, ctypes.c_void_p), count)
+        ws = _workspace(nbytes, dev)
+        rc = lib.lcrec_linear_backward_weights(ctypes.cast(arr, ctypes.c_void_p), count, _ptr(ws), ws.numel(), _stream_ptr())
+    _lib.check(rc, "lcrec_linear_backward_weights")
+
+
 def linear_backward_splits(n, in_dim, out_dim):
     """Number of batch runs whose partial products make up gw (part of the arithmetic contract, include/lcrec.h)."""
     return int(_lib.load().lcrec_linear_backward_splits(n, in_dim, out_dim))

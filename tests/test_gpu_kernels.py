@@ -71,6 +71,38 @@ def test_linear_backward_bit_exact(hip, oracle, n, k, out):
     assert only_gw[0] is None and torch.equal(only_gw[1], gw)
 
 
+def test_grouped_weight_gradients_equal_per_layer_calls(hip, oracle):
+    """lcrec_linear_backward_weights: the 14 weight gradients of a training step (run.sh widths, batch 1024 and a ragged
+    475) in one launch -- bit-identical to lcrec_linear_backward layer by layer (same K-runs, same order), which the test
+    above pins to the oracle; plus a 16-wide layer (out_dim % 32 != 0) and a single-problem call."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    widths = [768, 2048, 1024, 512, 256, 128, 64, 32]
+    for n in (1024, 475):
+        problems, want = [], []
+        for a, b in list(zip(widths[:-1], widths[1:])) + list(zip(widths[::-1][:-1], widths[::-1][1:])) + [(64, 16)]:
+            gy = torch.randn((n, b), generator=g, device=dev)
+            gy[torch.rand((n, b), generator=g, device=dev) < 0.4] = 0.0
+            x = torch.randn((n, a), generator=g, device=dev)
+            gw = torch.full((b, a), float("nan"), device=dev)
+            problems.append((gy, x, gw))
+            if b % 32 == 0:
+                want.append(hip.ops.linear_backward(gy, x, torch.empty((b, a), device=dev), need_gx=False)[1])
+            else:
+                _, gx_w = oracle.linear_backward(gy.cpu().numpy(), x.cpu().numpy(), np.zeros((b, a), np.float32),
+                                                 splits=hip.ops.linear_backward_splits(n, a, b), threads=8)
+                want.append(torch.from_numpy(gx_w).to(dev))
+        for lo in range(0, len(problems), 16):                     # at most 16 problems per launch
+            hip.ops.linear_backward_weights(problems[lo:lo + 16])
+        for (gy, x, gw), w in zip(problems, want):
+            assert torch.equal(gw, w), (n, tuple(gw.shape), (gw - w).abs().max().item())
+    one = torch.empty((2048, 768), device=dev)
+    hip.ops.linear_backward_weights([(problems[0][0], problems[0][1], one)])
+    assert torch.equal(one, problems[0][2])
+    with pytest.raises(hip.LcrecError):
+        hip.ops.linear_backward_weights([problems[0]] * 17)
+
+
 @pytest.mark.parametrize("n,e,Ks", [
     (64, 32, [256] * 4),
     (1000, 32, [256] * 4),
