@@ -17,6 +17,8 @@
 // 1024 x 2048 -- a third of the training step; 16 waves with 8 loads in flight each: see profiles/.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace lcrec {
 
 constexpr int CR_THREADS = 1024;  // 16 waves per strip: enough loads in flight to cover HBM/L2 latency from one CU
@@ -445,7 +447,13 @@ __global__ __launch_bounds__(256) void codebook_grad_kernel(const float *__restr
 
 // strip width by feature count: wide layers read 128-byte row segments; narrow ones take narrower strips so that more
 // than a handful of CUs work (their whole input is a few hundred KB)
-static int strip_cols(int F) { return F >= 1024 ? 32 : (F >= 256 ? 16 : 8); }
+static int strip_cols(int F)
+{
+    static const int forced = [] { const char *e = getenv("LCREC_STRIP_COLS"); return e ? atoi(e) : 0; }();   // tuning only
+    if (forced == 8 || forced == 16 || forced == 32) return forced;
+    if (forced == -1) return F >= 4096 ? 32 : (F >= 2048 ? 16 : 8);
+    return F >= 1024 ? 32 : (F >= 256 ? 16 : 8);
+}
 #define LCREC_STRIP_LAUNCH(KERN, F, stream, ...)                                                                      \
     do {                                                                                                              \
         const int cols_ = strip_cols(F);                                                                              \

@@ -1026,8 +1026,9 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     // K = 256 (the reference's codebook size): two rows per wave instead of four when that still fits 128 workgroups
     // (B <= 2048) -- twice the CUs on the divisions, 22.2 k -> 18.9 k cycles per iteration.  LCREC_SK_RW=4 disables.
     static const int rw_env = [] { const char *e = getenv("LCREC_SK_RW"); return e ? atoi(e) : 2; }();
-    const bool rw2 = rw_env == 2 && cpl == 4 && (B + 15) / 16 <= SKP_MAX_BLOCKS;
-    const int rows_p = rw2 ? 16 : cpl <= 4 ? 32 : (cpl <= 8 ? 16 : 8);
+    const bool rw1 = rw_env == 1 && cpl == 4 && (B + 7) / 8 <= SKP_MAX_BLOCKS;           // LCREC_SK_RW=1 (tuning): 8 rows per workgroup
+    const bool rw2 = !rw1 && rw_env <= 2 && cpl == 4 && (B + 15) / 16 <= SKP_MAX_BLOCKS;
+    const int rows_p = rw1 ? 8 : rw2 ? 16 : cpl <= 4 ? 32 : (cpl <= 8 ? 16 : 8);
     const int64_t nblk_p = (B + rows_p - 1) / rows_p;
     static const bool allow_persistent = [] { const char *e = getenv("LCREC_SINKHORN_PERSISTENT"); return !e || atoi(e) != 0; }();
     if (allow_persistent && nblk_p <= SKP_MAX_BLOCKS && nblk_p <= nblk * 4 && (3 * (int64_t)K + 1) * nblk_p + 3 * (int64_t)K <= B * (int64_t)K) {
@@ -1041,6 +1042,7 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
         bool launched;
         if (cpl <= 1) launched = launch_skp<1, 4>(q, stream);
         else if (cpl <= 2) launched = launch_skp<2, 4>(q, stream);
+        else if (rw1) launched = launch_skp<4, 1>(q, stream);
         else if (rw2) launched = launch_skp<4, 2>(q, stream);
         else if (cpl <= 4) launched = launch_skp<4, 4>(q, stream);
         else if (cpl <= 8) launched = launch_skp<8, 2>(q, stream);

@@ -67,6 +67,9 @@ def parse_args(argv=None):
     parser.add_argument("--strict_nan_check", action="store_true",
                         help="raise 'Training loss is nan' before the offending step's backward (a host sync per step, the "
                              "reference's timing) instead of one step later")
+    parser.add_argument("--reset_seed", type=int, default=None,
+                        help="seed a dedicated device generator for the dead-code reset draws of --ema_decay runs "
+                             "(default: torch's global generators, as the reference)")
     parser.add_argument("--train_engine", type=str, default="auto", choices=["auto", "off"],
                         help="auto = run the training step as one captured hipGraph when the configuration allows it "
                              "(lcrec_amd.engine); off = always the autograd path")
@@ -114,6 +117,9 @@ def main(argv=None):
     ctx = ldist.init_from_env(args)          # single process unless launched under torchrun
     data = EmbDataset(args.data_path)
     model = build_model(args, data.dim)
+    if getattr(args, "reset_seed", None) is not None and str(args.device).startswith("cuda"):
+        for l, q in enumerate(model.rq.vq_layers):      # one stream of draws per level, the same on every rank
+            q.reset_generator = torch.Generator(device=args.device).manual_seed(int(args.reset_seed) + l)
     if ctx.rank == 0:
         print(model)
     loader = DeviceLoader(data, batch_size=args.batch_size, shuffle=True, device=args.device, rank=ctx.rank,

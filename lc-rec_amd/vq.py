@@ -30,6 +30,9 @@ class VectorQuantizer(nn.Module):
         self.reset_threshold = reset_threshold
         self.reset_interval = reset_interval
         self.step_count = 0
+        # draws of the dead-code reset (index_improve/models/vq.py:79-114): None = torch's global generators, as the
+        # reference; a torch.Generator on the codebook's device (main.py --reset_seed) makes a run reproducible
+        self.reset_generator = None
 
         self.embedding = nn.Embedding(self.n_e, self.e_dim)
         if ema_decay is not None:
@@ -112,14 +115,15 @@ class VectorQuantizer(nn.Module):
             return 0
         num = min(num_unused, len(latent))
         dev = latent.device
-        sample = draws[0] if draws else torch.randint(0, len(latent), (num,), device=dev)
+        gen = self.reset_generator
+        sample = draws[0] if draws else torch.randint(0, len(latent), (num,), device=dev, generator=gen)
         vectors = latent[sample]
         if num_unused > num:
-            perm = draws[1] if draws else torch.randperm(num_unused, device=dev)
+            perm = draws[1] if draws else torch.randperm(num_unused, device=dev, generator=gen)
             target = unused[perm[:num]]
         else:
             target = unused
-        noise = (draws[2] if draws else torch.randn_like(vectors)) * 0.01
+        noise = (draws[2] if draws else torch.randn(vectors.shape, device=dev, dtype=vectors.dtype, generator=gen)) * 0.01
         self.embedding.weight.data[target] = (vectors + noise).detach()
         self._ema_cluster_size[target] = 0
         self._ema_w[target] = 0

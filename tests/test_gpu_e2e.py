@@ -93,6 +93,18 @@ def test_ema_training_runs_and_reports_utilisation(hip, tmp_path):
         "--eval_step", "2", "--batch_size", "128", "--layers", "32", "--e_dim", "16", "--num_emb_list", "32", "32",
         "--sk_epsilons", "0.0", "0.0", "--ema_decay", "0.99", "--reset_interval", "3", "--no_kmeans_init"])
     assert np.isfinite(best_loss) and 0.0 <= best_rate <= 1.0
+    # --reset_seed: the dead-code reset's draws (index_improve/models/vq.py:79-114; torch's global generators in the
+    # reference) come from a dedicated device generator, so two runs are identical -- weights, EMA buffers, everything
+    import glob
+    from lcrec_amd import generate_indices as gen
+    sds = []
+    for run in ("a", "b"):
+        cli.main(["--data_path", data_path, "--ckpt_dir", str(tmp_path / run), "--device", "cuda:0", "--epochs", "4",
+                  "--eval_step", "2", "--batch_size", "128", "--layers", "32", "--e_dim", "16", "--num_emb_list", "32", "32",
+                  "--sk_epsilons", "0.0", "0.0", "--ema_decay", "0.99", "--reset_interval", "3", "--no_kmeans_init",
+                  "--reset_threshold", "0.02", "--reset_seed", "7"])
+        sds.append(gen.load_checkpoint(glob.glob(str(tmp_path / run / "*" / "epoch_3_*"))[0])["state_dict"])
+    assert all(torch.equal(sds[0][k], sds[1][k]) for k in sds[0])
 
 
 def test_generate_reproduces_reference_index_json_bytes(hip, tmp_path):
