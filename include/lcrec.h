@@ -316,6 +316,20 @@ int lcrec_grad_norm_clip(const float *grads, int64_t count, float max_norm, floa
 int lcrec_codebook_grad(const float *count, const float *sum, const float *codebook, int K, int e, float scale,
                         float weight, float *grad_out, void *stream);
 
+/* The scalar tail of a training step in one launch: level losses mse_l + beta*mse_l with mse_l = sse[l]/(n*e)
+ * (index/models/vq.py:90-92), their mean (rq.py:53), loss = recon + quant_loss_weight * rq_loss (rqvae.py:83);
+ * losses_out[3] = {loss, recon, rq_loss}; sums_inout[2] += {loss, recon} (trainer.py:122-123; may be NULL);
+ * *nan_flag = 1 if the loss is NaN (trainer.py:116's check as a sticky device flag; may be NULL).  sse as written by
+ * lcrec_rq_assign / lcrec_rq_apply_level (device double[L]); recon a device float (lcrec_recon_loss_grad). */
+int lcrec_step_losses(const double *sse, int L, int64_t n, int e, float beta, float quant_loss_weight, const float *recon,
+                      float *losses_out, double *sums_inout, unsigned char *nan_flag, void *stream);
+
+/* Gradient reaching the encoder output z through the quantiser (autograd of vq.py:87-95 / rq.py:45-48):
+ * out = (coef * (z - C0[idx0])) * weight + g_xq, coef = beta * 2/(L*n*e), weight = d loss / d rq_loss; idx0 = the
+ * level-0 index column (element i at idx[i*idx_stride]); all [n][e]. */
+int lcrec_quantizer_input_grad(const float *z, const float *codebook0, const int64_t *idx, int64_t idx_stride, int64_t n,
+                               int e, float coef, float weight, const float *g_xq, float *out, void *stream);
+
 /* One optimiser step on flat fp32 buffers: torch.optim.AdamW (decoupled != 0) or Adam (index/trainer.py:49-81,119),
  * preceded by the clipping of index/trainer.py:118 (grads *= clip[1], stored back; clip may be NULL) and with the
  * learning rate of index/trainer.py:83-92,120 evaluated on the device from the step counter:

@@ -71,6 +71,10 @@ _SIGNATURES = {
     "lcrec_recon_loss_grad": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_grad_norm_clip": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_codebook_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    "lcrec_step_losses": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp,
+                                         _vp, _vp]),
+    "lcrec_quantizer_input_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                                  ctypes.c_float, _vp, _vp, _vp]),
     "lcrec_adamw_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int64, ctypes.c_int64, _vp, _vp]),

@@ -456,3 +456,15 @@ LCREC_API int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, in
 {
     return linear_backward_weights(problems, count, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+LCREC_API int lcrec_step_losses(const double *sse, int L, int64_t n, int e, float beta, float quant_loss_weight, const float *recon,
+                                float *losses_out, double *sums_inout, unsigned char *nan_flag, void *stream)
+{
+    return step_losses(sse, L, n, e, beta, quant_loss_weight, recon, losses_out, sums_inout, nan_flag, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_quantizer_input_grad(const float *z, const float *codebook0, const int64_t *idx, int64_t idx_stride, int64_t n,
+                                         int e, float coef, float weight, const float *g_xq, float *out, void *stream)
+{
+    return quantizer_input_grad(z, codebook0, idx, idx_stride, n, e, coef, weight, g_xq, out, (hipStream_t)stream);
+}

@@ -154,6 +154,10 @@ int recon_loss_grad(const float *out, const float *x, int64_t count, int l1, flo
                     size_t workspace_bytes, hipStream_t stream);
 int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_out, void *workspace, size_t workspace_bytes,
                    hipStream_t stream);
+int step_losses(const double *sse, int L, int64_t n, int e, float beta, float qlw, const float *recon, float *out3, double *sums2,
+                unsigned char *nan_flag, hipStream_t stream);
+int quantizer_input_grad(const float *z, const float *cb0, const int64_t *idx, int64_t idx_stride, int64_t n, int e, float coef,
+                         float weight, const float *g_xq, float *out, hipStream_t stream);
 int codebook_grad(const float *count, const float *sum, const float *cb, int K, int e, float scale, float weight, float *grad,
                   hipStream_t stream);
 int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const float *clip, int64_t *step, double base_lr,

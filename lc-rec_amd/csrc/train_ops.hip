@@ -431,6 +431,42 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(AdamParams a)
 
 __global__ void step_advance_kernel(int64_t *step) { *step += 1; }
 
+// The scalar tail of a step, one thread: level losses and their mean (vq.py:90-92, rq.py:53), total loss (rqvae.py:83),
+// the trainer's running sums (trainer.py:122-123) and its NaN check (trainer.py:116) as a sticky device flag.
+__global__ void step_losses_kernel(const double *sse, int L, double count, float beta, float qlw, const float *recon,
+                                   float *out3, double *sums2, unsigned char *nan_flag)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float mse = (float)(sse[l] / count);
+        acc += mse + beta * mse;
+    }
+    const float rq_loss = acc / (float)L;
+    const float rec = *recon;
+    const float loss = rec + qlw * rq_loss;
+    out3[0] = loss; out3[1] = rec; out3[2] = rq_loss;
+    if (sums2) { sums2[0] += (double)loss; sums2[1] += (double)rec; }
+    if (nan_flag && loss != loss) *nan_flag = 1;
+}
+
+// d loss / d z of the quantiser (quantize.py): (coef * (z - C0[idx0])) * weight + g_xq, coef = beta * 2/(L n e)
+__global__ __launch_bounds__(256) void quantizer_input_grad_kernel(const float *__restrict__ z, const float *__restrict__ cb0,
+                                                                   const int64_t *__restrict__ idx, int64_t idx_stride, int64_t n,
+                                                                   int e, float coef, float weight, const float *__restrict__ g_xq,
+                                                                   float *__restrict__ out)
+{
+    const int64_t total = n * e;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / e;
+        const int k = (int)(i - row * e);
+        const float t = z[i] - cb0[idx[row * idx_stride] * e + k];
+        const float u = coef * t;
+        const float v = u * weight;
+        out[i] = v + g_xq[i];
+    }
+}
+
 // dL/dC[k][:] = (scale * (count[k] * C[k][:] - sum[k][:])) * weight -- the closed form autograd derives from vq.py:90-92
 // (SURVEY.md a9), in the order quantize.py evaluates it
 __global__ __launch_bounds__(256) void codebook_grad_kernel(const float *__restrict__ count, const float *__restrict__ sum,
@@ -572,6 +608,30 @@ int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_ou
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, g, count, (double *)workspace);
     hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, max_norm, norm_out);
     return check_launch("grad_norm kernels");
+}
+
+int step_losses(const double *sse, int L, int64_t n, int e, float beta, float qlw, const float *recon, float *out3, double *sums2,
+                unsigned char *nan_flag, hipStream_t stream)
+{
+    if (!sse || !recon || !out3) return fail(LCREC_EINVAL, "step_losses: NULL pointer");
+    if (L < 1 || L > LCREC_MAX_LEVELS || n < 1 || e < 1) return fail(LCREC_EINVAL, "step_losses: bad shape");
+    TraceScope trace(K_LOSS, stream);
+    hipLaunchKernelGGL(step_losses_kernel, dim3(1), dim3(64), 0, stream, sse, L, (double)n * (double)e, beta, qlw, recon, out3, sums2, nan_flag);
+    return check_launch("step_losses_kernel");
+}
+
+int quantizer_input_grad(const float *z, const float *cb0, const int64_t *idx, int64_t idx_stride, int64_t n, int e, float coef,
+                         float weight, const float *g_xq, float *out, hipStream_t stream)
+{
+    if (n == 0) return LCREC_OK;
+    if (!z || !cb0 || !idx || !g_xq || !out) return fail(LCREC_EINVAL, "quantizer_input_grad: NULL pointer");
+    if (n < 0 || e < 1) return fail(LCREC_EINVAL, "quantizer_input_grad: bad shape");
+    int64_t blocks = (n * e + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    TraceScope trace(K_APPLY_LEVEL, stream);
+    hipLaunchKernelGGL(quantizer_input_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, cb0, idx, idx_stride, n, e, coef, weight,
+                       g_xq, out);
+    return check_launch("quantizer_input_grad_kernel");
 }
 
 int codebook_grad(const float *count, const float *sum, const float *cb, int K, int e, float scale, float weight, float *grad,

@@ -69,8 +69,7 @@ class TrainEngine:
         self.host_steps = self._prior_steps
         self.clip = torch.zeros(2, dtype=torch.float32, device=dev)          # (grad norm, clip coefficient) of the last step
         self.lr_used = torch.zeros((), dtype=torch.float32, device=dev)
-        self.loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        self.recon_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.sums = torch.zeros(2, dtype=torch.float64, device=dev)          # sum of losses / of reconstruction losses (epoch)
         self.last = torch.zeros(3, dtype=torch.float32, device=dev)          # loss, recon, rq_loss of the last step
         self.bad = torch.zeros(2, dtype=torch.bool, device=dev)              # [loss was NaN, Sinkhorn solver gave up]
         self._graphs = {}                                                    # batch rows -> (graph, static input)
@@ -193,19 +192,18 @@ class TrainEngine:
         if eager and any(not q.initted for q in levels):
             m.rq._lazy_kmeans(z.reshape(-1, m.e_dim), True)                 # vq.py:67-68, first training batch only
         cbs = [q.embedding.weight.data for q in levels]
-        q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), True, True, want_code_grads=False)
+        q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), True, True, want_code_grads=False, want_loss=False)
         out, dec = self._mlp_forward(m.decoder, q["xq"])
         counters = [s[2].num_batches_tracked for s in enc + dec if s[2] is not None]
         if counters:
             torch._foreach_add_(counters, 1)                                 # BatchNorm1d.num_batches_tracked, all layers at once
         recon, g_out = ops.recon_loss_grad(out, x, m.loss_type)
-        rq_loss = q["rq_loss"]
-        loss = recon + m.quant_loss_weight * rq_loss                         # rqvae.py:83
+        n, e = z.shape
+        # level losses, their mean, the total loss, the epoch's running sums and the NaN flag: one launch
+        ops.step_losses(q["sse"], n, e, float(m.rq.beta), m.quant_loss_weight, recon, self.last, self.sums, self.bad[0])
         dw = []
         g_xq = self._mlp_backward(dec, g_out, True, dw)
-        g_loss = torch.full((), float(m.quant_loss_weight), dtype=torch.float32, device=x.device)
-        gz = q["commit"] * g_loss
-        gz = gz + g_xq                                                       # quantize._Quantize.backward, same order
+        gz = ops.quantizer_input_grad(z, cbs[0], q["idx"][:, 0], float(m.rq.beta) * q["scale"], m.quant_loss_weight, g_xq)
         for lvl, cb, (cnt, tot) in zip(levels, cbs, q["stats"]):                 # (scale * (cnt*C - sum)) * g_loss, one launch per level
             ops.codebook_grad(cnt, tot, cb, q["scale"], m.quant_loss_weight, self.grad_view[lvl.embedding.weight])
         self._mlp_backward(enc, gz, False, dw)
@@ -215,10 +213,6 @@ class TrainEngine:
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.base_lr, self.betas, self.eps,
                        self.weight_decay, self.decoupled, clip=self.clip, schedule=self.schedule,
                        warmup_steps=self.warmup_steps, total_steps=self.total_steps, lr_out=self.lr_used)
-        self.loss_sum.add_(loss.double())
-        self.recon_sum.add_(recon.double())
-        self.last.copy_(torch.stack([loss, recon, rq_loss]))
-        self.bad[0].logical_or_(torch.isnan(loss))
         for _msg, flag in ops.deferred_checks.drain():                       # Sinkhorn poison flags of this step
             self.bad[1].logical_or_(flag)
 
@@ -254,13 +248,12 @@ class TrainEngine:
         self.graph_replays += 1
 
     def begin_epoch(self):
-        self.loss_sum.zero_()
-        self.recon_sum.zero_()
+        self.sums.zero_()
 
     def end_epoch(self, scheduler=None):
         """(sum of losses, sum of reconstruction losses) over the epoch's steps -- trainer.py:122-125 -- after checking
         the device-side flags; brings the host-side scheduler and optimizer bookkeeping up to date."""
-        vals = torch.stack([self.loss_sum, self.recon_sum]).cpu()
+        vals = self.sums.cpu()
         bad = self.bad.cpu()
         if bool(bad[1]):
             raise ops._lib.LcrecError("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "

@@ -677,6 +677,33 @@ def codebook_grad(count, total, codebook, scale, weight, out):
     return out
 
 
+def step_losses(sse, n, e, beta, quant_loss_weight, recon, losses_out, sums=None, nan_flag=None):
+    """losses_out[3] = (loss, recon, rq_loss) from the per-level sse (float64 [L]) and the reconstruction loss; optional
+    running sums (float64 [2], +=) and NaN flag (bool/uint8 scalar, set) -- lcrec_step_losses."""
+    lib = _lib.load()
+    if not (sse.is_cuda and sse.dtype == torch.float64 and sse.is_contiguous()):
+        raise _lib.LcrecError("sse must be a contiguous float64 device tensor")
+    with _on(sse.device):
+        rc = lib.lcrec_step_losses(_ptr(sse), sse.numel(), int(n), int(e), float(beta), float(quant_loss_weight), _ptr(recon),
+                                   _ptr(losses_out), _ptr(sums), _ptr(nan_flag), _stream_ptr())
+    _lib.check(rc, "lcrec_step_losses")
+    return losses_out
+
+
+def quantizer_input_grad(z, codebook0, idx_col, coef, weight, g_xq):
+    """(coef * (z - C0[idx0])) * weight + g_xq (lcrec_quantizer_input_grad)."""
+    lib = _lib.load()
+    z, codebook0, g_xq = _dev(z, "z"), _dev(codebook0, "codebook"), _dev(g_xq, "g_xq")
+    n, e = z.shape
+    idx_col, stride = _idx_col(idx_col, n)
+    out = torch.empty_like(z)
+    with _on(z.device):
+        rc = lib.lcrec_quantizer_input_grad(_ptr(z), _ptr(codebook0), _ptr(idx_col), stride, n, e, float(coef), float(weight),
+                                            _ptr(g_xq), _ptr(out), _stream_ptr())
+    _lib.check(rc, "lcrec_quantizer_input_grad")
+    return out
+
+
 def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=True,
                clip=None, schedule=-1, warmup_steps=0, total_steps=0, lr_out=None):
     """One AdamW/Adam step on flat fp32 buffers, all updated in place (see lcrec_adamw_step); `step` is a device int64

@@ -16,7 +16,7 @@ from . import dist as ldist
 from . import ops
 
 
-def quantize_values(zc, cbs, beta, plan, want_stats, training, want_code_grads=True):
+def quantize_values(zc, cbs, beta, plan, want_stats, training, want_code_grads=True, want_loss=True):
     """Values of the L-level quantiser on detached, contiguous inputs -- shared by the autograd node below and by the
     graph-captured training step (engine.py), which calls it without autograd.
     Returns dict(xq, rq_loss, idx, stats, resid_in, code_grads, commit); the last two (closed-form gradient factors, see
@@ -54,11 +54,14 @@ def quantize_values(zc, cbs, beta, plan, want_stats, training, want_code_grads=T
             resid_in[t] = resid[t - l]
         r = resid[m - l]
         l = m
-    # vq.py:90-92: loss_l = mse + beta*mse (fp32), rq.py:53: mean over levels
-    mse = (sse / float(n * e)).to(torch.float32)
-    level_loss = mse + beta * mse
-    out = {"xq": xq, "rq_loss": level_loss.mean(), "idx": idx, "stats": None, "resid_in": resid_in,
-           "code_grads": None, "commit": None}
+    # vq.py:90-92: loss_l = mse + beta*mse (fp32), rq.py:53: mean over levels  (the engine does this in lcrec_step_losses)
+    rq_loss = None
+    if want_loss:
+        mse = (sse / float(n * e)).to(torch.float32)
+        level_loss = mse + beta * mse
+        rq_loss = level_loss.mean()
+    out = {"xq": xq, "rq_loss": rq_loss, "idx": idx, "stats": None, "resid_in": resid_in,
+           "code_grads": None, "commit": None, "sse": sse}
     if want_stats:
         stats = [ops.code_stats(idx[:, t], resid_in[t], cbs[t].shape[0]) for t in range(L)]
         scale = 2.0 / (L * n * e)
