@@ -242,6 +242,17 @@ int lcrec_rq_apply_level(const float *resid_in, int64_t n, int e, const float *c
 int lcrec_code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K,
                      float *count, float *sum, void *stream);
 
+/* lcrec_code_stats for ALL levels of a quantiser in one launch, optionally fused with lcrec_codebook_grad:
+ *   idx      device [n][L] int64 (ResidualVectorQuantizer's index matrix, rq.py:54)
+ *   resid    HOST array of L device pointers, resid[l] [n][e] = the residual that entered level l
+ *   K        HOST [L];  count / sum: HOST arrays of L device pointers ([K[l]], [K[l]][e])
+ *   codebooks / grad_out: both NULL, or HOST arrays of L device pointers: grad_out[l] =
+ *            (scale * (count*C_l - sum)) * weight, see lcrec_codebook_grad
+ * Same bits as the per-level calls. */
+int lcrec_code_stats_levels(const int64_t *idx, const float *const *resid, int64_t n, int e, const int *K, int L,
+                            float *const *count, float *const *sum, const float *const *codebooks, float *const *grad_out,
+                            float scale, float weight, void *stream);
+
 /* EMA codebook update, index_improve/models/vq.py:155-184, in place:
  *   ema_count = ema_count*decay + alpha*count;  ema_sum = ema_sum*decay + alpha*sum;
  *   where ema_count > eps:  codebook = codebook*keep + (ema_sum/(ema_count+eps))*alpha.

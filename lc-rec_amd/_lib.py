@@ -55,6 +55,9 @@ _SIGNATURES = {
                                             ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_code_stats": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                         _vp, _vp, _vp]),
+    "lcrec_code_stats_levels": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                               ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                               ctypes.POINTER(_vp), ctypes.c_float, ctypes.c_float, _vp]),
     "lcrec_ema_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "lcrec_bn_relu_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp,

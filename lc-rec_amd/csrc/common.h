@@ -128,6 +128,8 @@ int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, con
                 hipStream_t stream);
 int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
                float *sum, hipStream_t stream);
+int code_stats_levels(const int64_t *idx, const float *const *resid, int64_t n, int e, const int *K, int L, float *const *count,
+                      float *const *sum, const float *const *cb, float *const *grad, float scale, float weight, hipStream_t stream);
 size_t collision_workspace(int64_t n, int L);
 int collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t *members_out, int64_t *offsets_out,
                      int64_t *counters_out, void *workspace, size_t workspace_bytes, hipStream_t stream);

@@ -1228,10 +1228,13 @@ constexpr int CSS_THREADS = 256;
 
 constexpr int CSS_CHUNK = 256;          // rows staged in LDS per pass of the summation
 
+// `bx` = which CSS_THREADS / E codes this workgroup sums.  cb / grad (both or neither): also write the codebook
+// gradient (scale * (count[k] * C[k] - sum[k])) * weight of those codes (lcrec_codebook_grad, fused).
 template <int E>
-__global__ __launch_bounds__(CSS_THREADS) void code_stats_sorted_kernel(const int64_t *__restrict__ idx, int64_t idx_stride,
-                                                                       const float *__restrict__ resid, int n, int K,
-                                                                       float *__restrict__ count, float *__restrict__ sum)
+__device__ __forceinline__ void code_stats_sorted_body(const int64_t *__restrict__ idx, int64_t idx_stride,
+                                                       const float *__restrict__ resid, int n, int K,
+                                                       float *__restrict__ count, float *__restrict__ sum, unsigned bx,
+                                                       const float *__restrict__ cb, float *__restrict__ grad, float scale, float weight)
 {
     __shared__ __attribute__((aligned(16))) unsigned short skey[CSS_MAX_N];     // code of item i
     __shared__ unsigned short order[CSS_MAX_N];                                 // items sorted by (code, item)
@@ -1265,14 +1268,14 @@ __global__ __launch_bounds__(CSS_THREADS) void code_stats_sorted_kernel(const in
         start[K] = run;
     }
     __syncthreads();
-    if (blockIdx.x == 0)
+    if (bx == 0)
         for (int k = tid; k < K; k += CSS_THREADS) count[k] = (float)cursor[k];
     // This workgroup sums CSS_THREADS / E codes: [k_lo, k_hi).  Stable placement of THEIR items only, by all threads:
     // thread (code c, segment g) owns items [g*seg, (g+1)*seg) -- it counts its matches, the segment counts of a code
     // are prefix-summed, then it appends its matches (item order inside a segment, segments in order).
     constexpr int CPB = CSS_THREADS / E;
     __shared__ int segcnt[CPB][E + 1];
-    const int k_lo = blockIdx.x * CPB, k_hi = k_lo + CPB < K ? k_lo + CPB : K;
+    const int k_lo = bx * CPB, k_hi = k_lo + CPB < K ? k_lo + CPB : K;
     {
         const int c = tid / E, g = tid % E;
         const unsigned k = (unsigned)(k_lo + c);
@@ -1324,7 +1327,41 @@ __global__ __launch_bounds__(CSS_THREADS) void code_stats_sorted_kernel(const in
         for (int p = a; p < b; ++p) acc = acc + rows[(p - c0) * E + d];      // the LDS reads run ahead of the add chain
         __syncthreads();
     }
-    if (k_lo + kq < K) sum[(size_t)(k_lo + kq) * E + d] = acc;
+    if (k_lo + kq < K) {
+        const size_t o = (size_t)(k_lo + kq) * E + d;
+        sum[o] = acc;
+        if (grad) {
+            const float t = (float)cursor[k_lo + kq] * cb[o] - acc;
+            grad[o] = (scale * t) * weight;
+        }
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(CSS_THREADS) void code_stats_sorted_kernel(const int64_t *__restrict__ idx, int64_t idx_stride,
+                                                                       const float *__restrict__ resid, int n, int K,
+                                                                       float *__restrict__ count, float *__restrict__ sum)
+{
+    code_stats_sorted_body<E>(idx, idx_stride, resid, n, K, count, sum, blockIdx.x, nullptr, nullptr, 0.f, 0.f);
+}
+
+// all levels of a quantiser in one launch: blockIdx.y = level
+struct CsLevels {
+    const int64_t *idx;          // [n][L]
+    int L, n;
+    float scale, weight;
+    const float *resid[LCREC_MAX_LEVELS], *cb[LCREC_MAX_LEVELS];
+    float *count[LCREC_MAX_LEVELS], *sum[LCREC_MAX_LEVELS], *grad[LCREC_MAX_LEVELS];
+    int K[LCREC_MAX_LEVELS];
+};
+
+template <int E>
+__global__ __launch_bounds__(CSS_THREADS) void code_stats_levels_kernel(CsLevels g)
+{
+    const int l = blockIdx.y;
+    if ((int)(blockIdx.x * (CSS_THREADS / E)) >= g.K[l]) return;
+    code_stats_sorted_body<E>(g.idx + l, g.L, g.resid[l], g.n, g.K[l], g.count[l], g.sum[l], blockIdx.x, g.cb[l], g.grad[l], g.scale,
+                              g.weight);
 }
 
 int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
@@ -1344,6 +1381,42 @@ int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64
     else if (e == 64) hipLaunchKernelGGL(code_stats_kernel<64>, dim3((K + 3) / 4), dim3(256), 0, stream, idx, idx_stride, resid, n, K, count, sum);
     else return fail(LCREC_EUNSUPPORTED, "code_stats: e_dim=%d (supported: 16, 32, 64)", e);
     return check_launch("code_stats_kernel");
+}
+
+int code_stats_levels(const int64_t *idx, const float *const *resid, int64_t n, int e, const int *K, int L, float *const *count,
+                      float *const *sum, const float *const *cb, float *const *grad, float scale, float weight, hipStream_t stream)
+{
+    if (!idx || !resid || !K || !count || !sum) return fail(LCREC_EINVAL, "code_stats_levels: NULL pointer");
+    if (L < 1 || L > LCREC_MAX_LEVELS || n < 1) return fail(LCREC_EINVAL, "code_stats_levels: bad L=%d or n=%lld", L, (long long)n);
+    if ((cb == nullptr) != (grad == nullptr)) return fail(LCREC_EINVAL, "code_stats_levels: codebooks and grad_out go together");
+    int kmax = 0;
+    bool fused = n <= CSS_MAX_N && (e == 16 || e == 32 || e == 64);
+    for (int l = 0; l < L; ++l) {
+        if (K[l] < 1 || !resid[l] || !count[l] || !sum[l] || (cb && (!cb[l] || !grad[l])))
+            return fail(LCREC_EINVAL, "code_stats_levels: level %d: bad K or NULL pointer", l);
+        kmax = K[l] > kmax ? K[l] : kmax;
+        fused = fused && K[l] <= CSS_MAX_K;
+    }
+    if (!fused) {                                   // sizes beyond the one-workgroup sort: level by level
+        for (int l = 0; l < L; ++l) {
+            int rc = code_stats(idx + l, L, resid[l], n, e, K[l], count[l], sum[l], stream);
+            if (!rc && cb) rc = codebook_grad(count[l], sum[l], cb[l], K[l], e, scale, weight, grad[l], stream);
+            if (rc) return rc;
+        }
+        return LCREC_OK;
+    }
+    CsLevels g = {};
+    g.idx = idx; g.L = L; g.n = (int)n; g.scale = scale; g.weight = weight;
+    for (int l = 0; l < L; ++l) {
+        g.resid[l] = resid[l]; g.count[l] = count[l]; g.sum[l] = sum[l]; g.K[l] = K[l];
+        g.cb[l] = cb ? cb[l] : nullptr; g.grad[l] = grad ? grad[l] : nullptr;
+    }
+    TraceScope trace(K_CODE_STATS, stream);
+    const dim3 grid((unsigned)((kmax * e + CSS_THREADS - 1) / CSS_THREADS), (unsigned)L);
+    if (e == 16) hipLaunchKernelGGL(code_stats_levels_kernel<16>, grid, dim3(CSS_THREADS), 0, stream, g);
+    else if (e == 32) hipLaunchKernelGGL(code_stats_levels_kernel<32>, grid, dim3(CSS_THREADS), 0, stream, g);
+    else hipLaunchKernelGGL(code_stats_levels_kernel<64>, grid, dim3(CSS_THREADS), 0, stream, g);
+    return check_launch("code_stats_levels_kernel");
 }
 
 int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,

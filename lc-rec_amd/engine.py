@@ -192,7 +192,7 @@ class TrainEngine:
         if eager and any(not q.initted for q in levels):
             m.rq._lazy_kmeans(z.reshape(-1, m.e_dim), True)                 # vq.py:67-68, first training batch only
         cbs = [q.embedding.weight.data for q in levels]
-        q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), True, True, want_code_grads=False, want_loss=False)
+        q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), False, True, want_loss=False)
         out, dec = self._mlp_forward(m.decoder, q["xq"])
         counters = [s[2].num_batches_tracked for s in enc + dec if s[2] is not None]
         if counters:
@@ -203,9 +203,11 @@ class TrainEngine:
         ops.step_losses(q["sse"], n, e, float(m.rq.beta), m.quant_loss_weight, recon, self.last, self.sums, self.bad[0])
         dw = []
         g_xq = self._mlp_backward(dec, g_out, True, dw)
-        gz = ops.quantizer_input_grad(z, cbs[0], q["idx"][:, 0], float(m.rq.beta) * q["scale"], m.quant_loss_weight, g_xq)
-        for lvl, cb, (cnt, tot) in zip(levels, cbs, q["stats"]):                 # (scale * (cnt*C - sum)) * g_loss, one launch per level
-            ops.codebook_grad(cnt, tot, cb, q["scale"], m.quant_loss_weight, self.grad_view[lvl.embedding.weight])
+        scale = 2.0 / (len(levels) * n * e)                                  # quantize.py: d mean-level-loss / d (sum of squares)
+        gz = ops.quantizer_input_grad(z, cbs[0], q["idx"][:, 0], float(m.rq.beta) * scale, m.quant_loss_weight, g_xq)
+        # per-code (count, sum) of every level and the codebook gradients (scale * (cnt*C - sum)) * g_loss: one launch
+        ops.code_stats_levels(q["idx"], q["resid_in"], [c.shape[0] for c in cbs], cbs,
+                              [self.grad_view[lvl.embedding.weight] for lvl in levels], scale, m.quant_loss_weight)
         self._mlp_backward(enc, gz, False, dw)
         ops.linear_backward_weights(dw)                                      # all 14 weight gradients, one launch
         del dw

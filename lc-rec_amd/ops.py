@@ -439,6 +439,31 @@ def code_stats(idx, resid, K):
     return count, total
 
 
+def code_stats_levels(idx, resid_in, ks, codebooks=None, grads_out=None, scale=0.0, weight=0.0):
+    """[(count, sum)] for every level of an [n, L] index matrix in one launch (lcrec_code_stats_levels); with codebooks and
+    grads_out (lists of [K_l, e] tensors) the codebook gradients (scale * (count*C - sum)) * weight are written too."""
+    lib = _lib.load()
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 2 and idx.is_contiguous()):
+        raise _lib.LcrecError("idx must be a contiguous int64 [n, L] device tensor")
+    n, L = idx.shape
+    resid = [_dev(r, "resid") for r in resid_in]
+    e = resid[0].shape[1]
+    dev = idx.device
+    counts = [torch.empty(int(k), dtype=torch.float32, device=dev) for k in ks]
+    sums = [torch.empty((int(k), e), dtype=torch.float32, device=dev) for k in ks]
+    PA = ctypes.c_void_p * L
+    fused = codebooks is not None
+    cbs = [_dev(c, "codebook") for c in codebooks] if fused else None
+    with _on(dev):
+        rc = lib.lcrec_code_stats_levels(_ptr(idx), PA(*[r.data_ptr() for r in resid]), n, e, _ints(ks), L,
+                                         PA(*[c.data_ptr() for c in counts]), PA(*[t.data_ptr() for t in sums]),
+                                         PA(*[c.data_ptr() for c in cbs]) if fused else None,
+                                         PA(*[g.data_ptr() for g in grads_out]) if fused else None, float(scale), float(weight),
+                                         _stream_ptr())
+    _lib.check(rc, "lcrec_code_stats_levels")
+    return list(zip(counts, sums))
+
+
 def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps):
     """In-place EMA step of index_improve vq.py:155-184 on three contiguous fp32 device tensors."""
     lib = _lib.load()

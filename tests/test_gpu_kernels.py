@@ -71,6 +71,33 @@ def test_linear_backward_bit_exact(hip, oracle, n, k, out):
     assert only_gw[0] is None and torch.equal(only_gw[1], gw)
 
 
+@pytest.mark.parametrize("n,e,Ks", [(1024, 32, [256] * 4), (475, 16, [32, 256, 7]), (2048, 32, [1024] * 8), (9000, 32, [64, 64])])
+def test_code_stats_levels_equal_per_level_calls(hip, oracle, n, e, Ks):
+    """lcrec_code_stats_levels: (count, sum) of every level and the fused codebook gradient in one launch -- the same bits as
+    lcrec_code_stats (pinned to the CPU's index_add_ order by the oracle) + lcrec_codebook_grad per level; n = 9000 is
+    beyond the one-workgroup sort and takes the level-by-level path."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(n + e)
+    L = len(Ks)
+    idx = torch.stack([torch.randint(0, K, (n,), generator=g, device=dev) for K in Ks], 1).contiguous()
+    idx[: n // 2, 0] = 3                                           # one code owns half the batch (early training)
+    resid = [torch.randn((n, e), generator=g, device=dev) for _ in Ks]
+    cbs = [torch.randn((K, e), generator=g, device=dev) for K in Ks]
+    grads = [torch.full((K, e), float("nan"), device=dev) for K in Ks]
+    got = hip.ops.code_stats_levels(idx, resid, Ks, cbs, grads, scale=1.7e-4, weight=0.5)
+    for l, K in enumerate(Ks):
+        cnt, tot = hip.ops.code_stats(idx[:, l], resid[l], K)
+        assert torch.equal(got[l][0], cnt) and torch.equal(got[l][1], tot)
+        want = torch.empty((K, e), device=dev)
+        hip.ops.codebook_grad(cnt, tot, cbs[l], 1.7e-4, 0.5, want)
+        assert torch.equal(grads[l], want)
+        assert torch.equal(want, (1.7e-4 * (cnt.unsqueeze(1) * cbs[l] - tot)) * 0.5)       # quantize.py's expression
+        oc, os_ = oracle.code_stats(idx[:, l].cpu().numpy(), resid[l].cpu().numpy(), K)
+        assert np.array_equal(cnt.cpu().numpy(), oc) and np.array_equal(tot.cpu().numpy(), os_)
+    plain = hip.ops.code_stats_levels(idx, resid, Ks)              # statistics only
+    assert all(torch.equal(a[1], b[1]) for a, b in zip(plain, got))
+
+
 def test_grouped_weight_gradients_equal_per_layer_calls(hip, oracle):
     """lcrec_linear_backward_weights: the 14 weight gradients of a training step (run.sh widths, batch 1024 and a ragged
     475) in one launch -- bit-identical to lcrec_linear_backward layer by layer (same K-runs, same order), which the test
