@@ -92,7 +92,11 @@ struct Strip {
 
 // Training-mode BatchNorm1d (+ReLU).  torch semantics: batch mean, biased variance for the normalisation,
 // running_mean/var updated with `momentum` (running_var from the unbiased variance), eps inside the square root.
-template <int COLS>
+// CACHED (n <= CR_MAXR rows per lane): the lane's rows stay in registers between the statistics pass and the apply pass --
+// t is read from memory once.  Same sums in the same order as the two-pass form, hence the same bits.
+constexpr int CR_MAXR = 32;
+
+template <int COLS, bool CACHED>
 __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_kernel(const float *__restrict__ t, int64_t n, int F,
                                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                       float eps, float momentum, float *running_mean,
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_kernel(const float
                                                                       float *rstd_out, int relu)
 {
     __shared__ float sm[CR_WAVES][COLS];
+    constexpr int RGS = Strip<COLS>::RGS;
     const Strip<COLS> st(F);
     const int col = st.live ? st.col : 0;          // dead lanes read column 0 and write nothing
     const float inv_n = 1.0f / (float)n;
@@ -108,8 +113,22 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_kernel(const float
     // column -- so |mean - pivot| is of the order of the standard deviation and m2 = s2 - s1^2/n loses a bit or two, not
     // the digits the textbook E[t^2] - mean^2 loses when |mean| >> std
     const float pivot = tc[0];
-    float s1, s2;
-    st.rows2(n, s1, s2, [&](int64_t r, float &a, float &b) { const float d = tc[r * F] - pivot; a = d; b = d * d; });
+    float tv[CACHED ? CR_MAXR : 1];
+    float s1 = 0.f, s2 = 0.f;
+    if (CACHED) {
+#pragma unroll
+        for (int u = 0; u < CR_MAXR; ++u) {
+            const int64_t r = st.rg + (int64_t)u * RGS;
+            tv[u] = r < n ? tc[r * F] : pivot;
+        }
+#pragma unroll
+        for (int u = 0; u < CR_MAXR; ++u) {
+            const float d = tv[u] - pivot;          // rows past n contribute exact zeros, which change no sum
+            if (st.rg + (int64_t)u * RGS < n) { s1 += d; s2 += d * d; }
+        }
+    } else {
+        st.rows2(n, s1, s2, [&](int64_t r, float &a, float &b) { const float d = tc[r * F] - pivot; a = d; b = d * d; });
+    }
     s1 = st.sum(s1, sm);
     s2 = st.sum(s2, sm);
     const float dmean = s1 * inv_n;
@@ -121,11 +140,23 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_kernel(const float
     if (!st.live) return;
     const float g = gamma ? gamma[col] : 1.0f, b = beta ? beta[col] : 0.0f;
     float *yc = y + col;
+    if (CACHED) {
+#pragma unroll
+        for (int u = 0; u < CR_MAXR; ++u) {
+            const int64_t r = st.rg + (int64_t)u * RGS;
+            if (r < n) {
+                float v = (tv[u] - mean) * rstd * g + b;
+                if (relu) v = v > 0.f ? v : 0.f;
+                yc[r * F] = v;
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int64_t r = st.rg; r < n; r += Strip<COLS>::RGS) {
-        float v = (tc[r * F] - mean) * rstd * g + b;
-        if (relu) v = v > 0.f ? v : 0.f;
-        yc[r * F] = v;
+        for (int64_t r = st.rg; r < n; r += RGS) {
+            float v = (tc[r * F] - mean) * rstd * g + b;
+            if (relu) v = v > 0.f ? v : 0.f;
+            yc[r * F] = v;
+        }
     }
     if (st.rg == 0) {
         mean_out[col] = mean;
@@ -141,7 +172,7 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_kernel(const float
 // Backward of y = [relu](bn(t)) for gy = dL/dy:
 //   g = gy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;  dt = gamma * rstd * (g - dbeta/n - xhat * dgamma/n)
 // and the gradient of the Linear bias that produced t: dbias = sum dt (zero up to rounding, as in autograd).
-template <int COLS>
+template <int COLS, bool CACHED>
 __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const float *gy, const float *__restrict__ t,
                                                                        const float *__restrict__ y, int64_t n, int F,
                                                                        const float *__restrict__ gamma, const float *__restrict__ mean,
@@ -149,13 +180,28 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const floa
                                                                        float *dgamma, float *dbeta, float *dbias)
 {
     __shared__ float sm[CR_WAVES][COLS];
+    constexpr int RGS = Strip<COLS>::RGS;
     const Strip<COLS> st(F);
     const int col = st.live ? st.col : 0;
     const float mu = mean[col], rs = rstd[col], gm = gamma ? gamma[col] : 1.0f;
     const float *gc = gy + col, *tc = t + col, *yc = relu ? y + col : nullptr;
     auto gval = [&](int64_t r) { float g = gc[r * F]; if (relu && !(yc[r * F] > 0.f)) g = 0.f; return g; };
-    float db, dg;
-    st.rows2(n, db, dg, [&](int64_t r, float &a, float &b) { const float g = gval(r); a = g; b = g * ((tc[r * F] - mu) * rs); });
+    float gv[CACHED ? CR_MAXR : 1], xv[CACHED ? CR_MAXR : 1];     // CACHED: the lane's masked gradients and xhat, read once
+    float db = 0.f, dg = 0.f;
+    if (CACHED) {
+#pragma unroll
+        for (int u = 0; u < CR_MAXR; ++u) {
+            const int64_t r = st.rg + (int64_t)u * RGS;
+            const bool in = r < n;
+            gv[u] = in ? gval(r) : 0.f;
+            xv[u] = in ? (tc[r * F] - mu) * rs : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < CR_MAXR; ++u)
+            if (st.rg + (int64_t)u * RGS < n) { db += gv[u]; dg += gv[u] * xv[u]; }
+    } else {
+        st.rows2(n, db, dg, [&](int64_t r, float &a, float &b) { const float g = gval(r); a = g; b = g * ((tc[r * F] - mu) * rs); });
+    }
     db = st.sum(db, sm);
     dg = st.sum(dg, sm);
     const float inv_n = 1.0f / (float)n;
@@ -163,12 +209,24 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const floa
     float *dc = dt + col;
     float sdt = 0.f;
     if (st.live) {
+        if (CACHED) {
+#pragma unroll
+            for (int u = 0; u < CR_MAXR; ++u) {
+                const int64_t r = st.rg + (int64_t)u * RGS;
+                if (r < n) {
+                    const float v = k * (gv[u] - mdb - xv[u] * mdg);
+                    dc[r * F] = v;
+                    sdt += v;
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int64_t r = st.rg; r < n; r += Strip<COLS>::RGS) {
-            const float xh = (tc[r * F] - mu) * rs;
-            const float v = k * (gval(r) - mdb - xh * mdg);
-            dc[r * F] = v;
-            sdt += v;
+            for (int64_t r = st.rg; r < n; r += RGS) {
+                const float xh = (tc[r * F] - mu) * rs;
+                const float v = k * (gval(r) - mdb - xh * mdg);
+                dc[r * F] = v;
+                sdt += v;
+            }
         }
     }
     const float dbs = st.sum(sdt, sm);
@@ -499,6 +557,21 @@ static int strip_cols(int F)
         else hipLaunchKernelGGL(KERN<8>, grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);                            \
     } while (0)
 
+// the same for the kernels with a register-cached form: narrower strips when that lets the lane's rows fit (n <= 32 rows per
+// lane: 1024 rows at 32 columns, 2048 at 16, 4096 at 8), the cached form whenever they do
+#define LCREC_STRIP_LAUNCH_N(KERN, F, n, stream, ...)                                                                  \
+    do {                                                                                                              \
+        int cols_ = strip_cols(F);                                                                                    \
+        while (cols_ > 8 && (int64_t)(n) > (int64_t)CR_MAXR * (CR_THREADS / cols_)) cols_ /= 2;                       \
+        /* measured (768-d recipe): at 1024 rows the second pass hits L2 anyway and the cached form is ~1 % slower; at */ \
+        /* 2048 rows the narrower strips + cached rows are ~3 % of the step faster                                    */ \
+        const bool cached_ = (int64_t)(n) > 1024 && (int64_t)(n) <= (int64_t)CR_MAXR * (CR_THREADS / cols_);          \
+        const dim3 grid_((unsigned)(((F) + cols_ - 1) / cols_));                                                      \
+        if (cols_ == 32) { if (cached_) hipLaunchKernelGGL((KERN<32, true>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((KERN<32, false>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); } \
+        else if (cols_ == 16) { if (cached_) hipLaunchKernelGGL((KERN<16, true>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((KERN<16, false>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); } \
+        else { if (cached_) hipLaunchKernelGGL((KERN<8, true>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((KERN<8, false>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); } \
+    } while (0)
+
 int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const float *beta, float eps, float momentum,
                     float *running_mean, float *running_var, float *y, float *mean_out, float *rstd_out, int relu,
                     hipStream_t stream)
@@ -508,8 +581,8 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
     if (n < 2) return fail(LCREC_EINVAL, "bn_relu_forward: training-mode BatchNorm needs more than 1 row (n=%lld)", (long long)n);
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_forward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_FWD, stream);
-    LCREC_STRIP_LAUNCH(bn_relu_forward_kernel, F, stream, t, n, F, gamma, beta, eps, momentum, running_mean, running_var, y,
-                       mean_out, rstd_out, relu);
+    LCREC_STRIP_LAUNCH_N(bn_relu_forward_kernel, F, n, stream, t, n, F, gamma, beta, eps, momentum, running_mean, running_var, y,
+                         mean_out, rstd_out, relu);
     return check_launch("bn_relu_forward_kernel");
 }
 
@@ -520,7 +593,7 @@ int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n,
     if (!gy || !t || !mean || !rstd || !dt || (relu && !y)) return fail(LCREC_EINVAL, "bn_relu_backward: NULL pointer");
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_backward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_BWD, stream);
-    LCREC_STRIP_LAUNCH(bn_relu_backward_kernel, F, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias);
+    LCREC_STRIP_LAUNCH_N(bn_relu_backward_kernel, F, n, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias);
     return check_launch("bn_relu_backward_kernel");
 }
 
