@@ -54,9 +54,20 @@ __device__ unsigned long long g_marks[8][4];      // kernel entry, prologue done
             g_stamps[wave][2 * u + half][slot] = t_;                                               \
         }                                                                                          \
     } while (0)
+// generic (non ping-pong) kernel: workgroup with tile number 9, lane 0 of each wave, first 64 K-tiles, 6 points per K-tile
+__device__ unsigned long long g_gen_stamps[4][64][6];
+#define LCREC_GSTAMP(slot)                                                                         \
+    do {                                                                                           \
+        if (bid == 9 && split == 0 && lane == 0 && kt - kt0 < 64) {                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            g_gen_stamps[wave][kt - kt0][slot] = t_;                                               \
+        }                                                                                          \
+    } while (0)
 #else
 #define LCREC_STAMP(slot) do { } while (0)
 #define LCREC_MARK(slot) do { } while (0)
+#define LCREC_GSTAMP(slot) do { } while (0)
 #endif
 
 template <int N>
@@ -245,8 +256,12 @@ __device__ __forceinline__ void linear_tile_body(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    StageRegs<BM> ra;
-    StageRegs<BN> rw;
+    // two register sets: the global loads of K-tile kt+2 are issued before K-tile kt's MFMAs (prefetch distance 2).
+    // rocprofv3 counters on the batch-sized launches (1024 x 2048 -> 1024: 256 workgroups, one per CU) showed where the
+    // time goes: MFMA busy 48 % of the kernel, 55 % of every wave's cycles in s_waitcnt, four fifths of that on vmcnt --
+    // one K-tile (16 KB per workgroup) in flight against a ~2 000-cycle loaded latency is Little's law, not arithmetic.
+    StageRegs<BM> ra, ra2;
+    StageRegs<BN> rw, rw2;
     // split K (backward dW only, where K is the batch and the output is small): workgroup (tile, blockIdx.y) runs the
     // K-tiles [kt0, nk) of its split and writes a partial result at C + blockIdx.y * split_stride; a second kernel adds
     // the partials in split order.  Forward launches pass kt_per_split = all K-tiles, gridDim.y = 1.
@@ -270,14 +285,21 @@ __device__ __forceinline__ void linear_tile_body(
     const __amdgpu_buffer_rsrc_t w_rsrc = TB ? kmajor_rsrc(W, n0, N, BN) : tile_rsrc(W, n0, N, BN, K);
     // k-major staging: thread p of a pass loads the 16 bytes at (k = p / (ROWS/4), rows 4*(p % (ROWS/4)) .. +3) and
     // writes them to four LDS rows at k's de-interleaved slot (k steps of 8+ between passes keep the slot's low bits)
-    auto kmajor_load = [&](auto &r, __amdgpu_buffer_rsrc_t rs, auto rows_c, int64_t R, int64_t r0, int kt) {
+    // `live` (uniform): a K-tile past the end of this workgroup's run is still "loaded" -- with a scalar offset beyond the
+    // descriptor's extent, so the range check returns zeros without touching memory.  The loads must be unconditional:
+    // behind a branch, the compiler's s_waitcnt insertion merges the two paths and makes the LDS store of K-tile kt+1 wait
+    // for vmcnt(0), i.e. for the loads of kt+2 just issued -- which is what made prefetch distance 2 worthless at first.
+    constexpr unsigned SOFF_OUT = 0x7fffff00u;
+    auto kmajor_load = [&](auto &r, __amdgpu_buffer_rsrc_t rs, auto rows_c, int64_t R, int64_t r0, int kt, bool live) {
         constexpr int ROWS = decltype(rows_c)::value, Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;
         const int kk = tid / Q, r4 = tid % Q;
         const bool ok = tid < Q * 32 && r0 + r4 * 4 < R;
         const int vo = ok ? (int)((kk * R + r4 * 4) * 4) : 0x7fffff00;
 #pragma unroll
-        for (int j = 0; j < NL; ++j)
-            r.v[j >> 1][j & 1] = buffer_load_f32x4(rs, vo, (int)(((int64_t)kt * BK + j * KSTEP) * R * 4));
+        for (int j = 0; j < NL; ++j) {
+            const unsigned so = live ? (unsigned)(((int64_t)kt * BK + j * KSTEP) * R * 4) : SOFF_OUT;
+            r.v[j >> 1][j & 1] = buffer_load_f32x4(rs, vo, (int)so);
+        }
     };
     auto kmajor_store = [&](const auto &r, float *lds, auto rows_c) {
         constexpr int ROWS = decltype(rows_c)::value, Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;
@@ -296,15 +318,15 @@ __device__ __forceinline__ void linear_tile_body(
     };
     const int t_g = ((tid >> 2) * K + (tid & 3) * 8) * 4;
     const uint32_t t_s = (uint32_t)(((tid >> 2) * LDK + (tid & 3) * 8) * 4);
-    auto fast_load = [&](auto &r, __amdgpu_buffer_rsrc_t rs, int rows, int kt) {
+    auto fast_load = [&](auto &r, __amdgpu_buffer_rsrc_t rs, int rows, int kt, bool live) {
         constexpr int IT = sizeof(r.v) / sizeof(r.v[0]);
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const bool in_tile = (tid >> 2) + it * 64 < rows;
             const int vo = in_tile ? t_g : 0x7fffff00;
-            const int so = kt * (BK * 4) + it * 64 * K * 4;
-            r.v[it][0] = buffer_load_f32x4(rs, vo, so);
-            r.v[it][1] = buffer_load_f32x4(rs, vo + 16, so);
+            const unsigned so = live ? (unsigned)(kt * (BK * 4) + it * 64 * K * 4) : SOFF_OUT;   // (0x7fffff00 twice still < 2^32)
+            r.v[it][0] = buffer_load_f32x4(rs, vo, (int)so);
+            r.v[it][1] = buffer_load_f32x4(rs, vo + 16, (int)so);
         }
     };
     auto fast_store = [&](const auto &r, float *lds, int rows) {
@@ -313,41 +335,46 @@ __device__ __forceinline__ void linear_tile_body(
         for (int it = 0; it < IT; ++it)
             if ((tid >> 2) + it * 64 < rows) lds_store_deint8(lds_addr(lds) + t_s + it * 64 * LDK * 4, r.v[it][0], r.v[it][1]);
     };
-    auto stage_in = [&](int kt) {
+    auto stage_in = [&](int kt, StageRegs<BM> &ra_, StageRegs<BN> &rw_, bool live) {
         if constexpr (FAST) {
-            if constexpr (TA) kmajor_load(ra, a_rsrc, IntC<BM>{}, M, m0, kt);
-            else fast_load(ra, a_rsrc, BM, kt);
-            if constexpr (TB) kmajor_load(rw, w_rsrc, IntC<BN>{}, N, n0, kt);
-            else fast_load(rw, w_rsrc, BN, kt);
-        } else {
-            stage_load<BM>(ra, A, m0, M, K, kt * BK, tid);
-            stage_load<BN>(rw, W, n0, N, K, kt * BK, tid);
+            if constexpr (TA) kmajor_load(ra_, a_rsrc, IntC<BM>{}, M, m0, kt, live);
+            else fast_load(ra_, a_rsrc, BM, kt, live);
+            if constexpr (TB) kmajor_load(rw_, w_rsrc, IntC<BN>{}, N, n0, kt, live);
+            else fast_load(rw_, w_rsrc, BN, kt, live);
+        } else if (live) {
+            stage_load<BM>(ra_, A, m0, M, K, kt * BK, tid);
+            stage_load<BN>(rw_, W, n0, N, K, kt * BK, tid);
         }
     };
-    auto stage_out = [&]() {
+    auto stage_out = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_) {
         if constexpr (FAST) {
-            if constexpr (TA) kmajor_store(ra, As, IntC<BM>{});
-            else fast_store(ra, As, BM);
-            if constexpr (TB) kmajor_store(rw, Ws, IntC<BN>{});
-            else fast_store(rw, Ws, BN);
+            if constexpr (TA) kmajor_store(ra_, As, IntC<BM>{});
+            else fast_store(ra_, As, BM);
+            if constexpr (TB) kmajor_store(rw_, Ws, IntC<BN>{});
+            else fast_store(rw_, Ws, BN);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm stores are invisible to the compiler's counters
         } else {
-            stage_store<BM>(ra, As, tid);
-            stage_store<BN>(rw, Ws, tid);
+            stage_store<BM>(ra_, As, tid);
+            stage_store<BN>(rw_, Ws, tid);
         }
     };
 
     if (kt0 < nk) {
-        stage_in(kt0);
-        stage_out();
+        stage_in(kt0, ra, rw, true);
+        stage_out(ra, rw);
+        stage_in(kt0 + 1, ra2, rw2, kt0 + 1 < nk);        // K-tile kt0+1 waits in the second set
     }
     __syncthreads();
 
     const float *a_base = As + (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     const float *w_base = Ws + (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
 
-    for (int kt = kt0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage_in(kt + 1);
+    // one K-tile: loads of kt+2 into the set `ra_free` (K-tile kt left it for LDS an iteration ago), MFMAs of kt from LDS,
+    // then K-tile kt+1 -- loaded a whole iteration ago into `ra_next` -- goes to LDS
+    auto k_tile = [&](int kt, StageRegs<BM> &ra_free, StageRegs<BN> &rw_free, const StageRegs<BM> &ra_next, const StageRegs<BN> &rw_next) {
+        LCREC_GSTAMP(0);
+        stage_in(kt + 2, ra_free, rw_free, kt + 2 < nk);
+        LCREC_GSTAMP(1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 af[TM], wf[TN];
@@ -366,11 +393,19 @@ __device__ __forceinline__ void linear_tile_body(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], wf[j][q],
                                                                          acc[i][j], 0, 0, 0);
         }
+        LCREC_GSTAMP(2);
         __syncthreads();
+        LCREC_GSTAMP(3);
         if (kt + 1 < nk) {
-            stage_out();
+            stage_out(ra_next, rw_next);
+            LCREC_GSTAMP(4);
             __syncthreads();
         }
+        LCREC_GSTAMP(5);
+    };
+    for (int kt = kt0; kt < nk; kt += 2) {                  // unrolled by two so that both register sets are static
+        k_tile(kt, ra, rw, ra2, rw2);
+        if (kt + 1 < nk) k_tile(kt + 1, ra2, rw2, ra, rw);
     }
 
     // epilogue (every wave passed the loop's last barrier after its final LDS operand read, so the
@@ -1370,6 +1405,9 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
         // batch-sized problems (a training step has 1-2 k rows): 128 x 128 tiles would leave most CUs idle,
         // so launches with fewer than two tiles per CU use 64 x 64 tiles (4x the workgroups)
         const int64_t tiles128 = ((n + 127) / 128) * ((out_dim + 127) / 128);
+        static const int small_tile = [] { const char *e = getenv("LCREC_GEMM_SMALL"); return e ? atoi(e) : 0; }();   // tuning only
+        if (tiles128 < 512 && small_tile == 1) return launch_linear<2, 2, 1, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
+        if (tiles128 < 512 && small_tile == 2) return launch_linear<2, 2, 2, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
         if (tiles128 < 512) return launch_linear<2, 2, 1, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
         return launch_linear<2, 2, 2, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
     }
@@ -1383,6 +1421,10 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
 extern "C" __attribute__((visibility("default"))) int lcrec_debug_gemm_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcrec::g_stamps), sizeof(unsigned long long) * 8 * 64 * 4);
+}
+extern "C" __attribute__((visibility("default"))) int lcrec_debug_generic_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lcrec::g_gen_stamps), sizeof(unsigned long long) * 4 * 64 * 6);
 }
 extern "C" __attribute__((visibility("default"))) int lcrec_debug_gemm_marks(unsigned long long *out)
 {
