@@ -219,7 +219,14 @@ __device__ __forceinline__ void linear_tile_body(
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     // one allocation: the epilogue stages 4 x 32 output rows from its start, which is more than As when BM = 64
     static_assert(BM + BN >= 128, "the epilogue needs 128 staging rows");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    // DB (the 64 x 64 tile of batch-sized launches): two LDS buffers, ONE barrier per K-tile, and K-tile kt+1's LDS stores
+    // issued between K-tile kt's MFMAs.  In-kernel stamps (tools/generic_stamp_probe.py) had the stores at 670 of a K-tile's
+    // 2 500 cycles: every ds_write2_b32 of the de-interleaving store hits 8 of the 32 banks (all bases are multiples of 4
+    // dwords, both halves of a pair land on the same residue), and with one workgroup per CU nothing ran under them.  In
+    // the second buffer they run under the 1 024 cycles the MFMA pipe needs anyway.
+    constexpr bool DB = FAST && TM == 1 && TN == 1;
+    constexpr int BUF = (BM + BN) * LDK;
+    __shared__ __attribute__((aligned(16))) float smem[BUF * (DB ? 2 : 1)];
     float *const As = smem, *const Ws = smem + BM * LDK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -346,6 +353,13 @@ __device__ __forceinline__ void linear_tile_body(
             stage_load<BN>(rw_, W, n0, N, K, kt * BK, tid);
         }
     };
+    // (DB only) the stores alone, into buffer `buf`; the caller waits for them (lgkmcnt) before its barrier
+    auto stage_out_into = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_, int buf) {
+        if constexpr (TA) kmajor_store(ra_, As + buf * BUF, IntC<BM>{});
+        else fast_store(ra_, As + buf * BUF, BM);
+        if constexpr (TB) kmajor_store(rw_, Ws + buf * BUF, IntC<BN>{});
+        else fast_store(rw_, Ws + buf * BUF, BN);
+    };
     auto stage_out = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_) {
         if constexpr (FAST) {
             if constexpr (TA) kmajor_store(ra_, As, IntC<BM>{});
@@ -403,9 +417,43 @@ __device__ __forceinline__ void linear_tile_body(
         }
         LCREC_GSTAMP(5);
     };
-    for (int kt = kt0; kt < nk; kt += 2) {                  // unrolled by two so that both register sets are static
-        k_tile(kt, ra, rw, ra2, rw2);
-        if (kt + 1 < nk) k_tile(kt + 1, ra2, rw2, ra, rw);
+    // DB form of the same K-tile: reads buffer `cur`, stores K-tile kt+1 into the other one between the MFMA groups.  The
+    // stores are unconditional (past the end the registers hold the zeros of an out-of-range load and nobody reads the
+    // buffer), so there is no branch for the compiler's waitcnt bookkeeping to merge over.
+    auto k_tile_db = [&](int kt, StageRegs<BM> &ra_free, StageRegs<BN> &rw_free, const StageRegs<BM> &ra_next, const StageRegs<BN> &rw_next,
+                         auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        stage_in(kt + 2, ra_free, rw_free, kt + 2 < nk);
+        f32x4 af[4], wf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            af[g] = *reinterpret_cast<const f32x4 *>(a_base + cur * BUF + g * 8);
+            wf[g] = *reinterpret_cast<const f32x4 *>(w_base + cur * BUF + g * 8);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][q], wf[g][q], acc[0][0], 0, 0, 0);
+            if (g == 0) {                                   // the first four MFMAs are queued: now the stores
+                __builtin_amdgcn_sched_barrier(0);
+                stage_out_into(ra_next, rw_next, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads of `cur` and stores into the other buffer
+        __syncthreads();
+    };
+    if constexpr (DB) {
+        for (int kt = kt0; kt < nk; kt += 2) {
+            k_tile_db(kt, ra, rw, ra2, rw2, IntC<0>{});
+            if (kt + 1 < nk) k_tile_db(kt + 1, ra2, rw2, ra, rw, IntC<1>{});
+        }
+    } else {
+        for (int kt = kt0; kt < nk; kt += 2) {              // unrolled by two so that both register sets are static
+            k_tile(kt, ra, rw, ra2, rw2);
+            if (kt + 1 < nk) k_tile(kt + 1, ra2, rw2, ra, rw);
+        }
     }
 
     // epilogue (every wave passed the loop's last barrier after its final LDS operand read, so the
