@@ -32,8 +32,9 @@ at 2048 (2.51 -> 2.45).  With ONE fork/join (the decoder's seven weight gradient
 chain) nothing changes at 1024 (1.80 -> 1.82) and little at 2048 (2.51 -> 2.46): the replayed graph does not run the two
 branches' under-filled kernels side by side to any useful degree.
 
-What the engine does not cover falls back to the autograd path in trainer.py, unchanged: data-parallel runs, the EMA
-codebook update of index_improve/, dropout > 0, activations other than ReLU, optimisers other than Adam/AdamW,
+The EMA codebook update of index_improve/ is part of the captured step (lcrec_ema_update); the steps on which a dead-code
+reset is due run eagerly.  What the engine does not cover falls back to the autograd path in trainer.py, unchanged:
+data-parallel runs, dropout > 0, activations other than ReLU, optimisers other than Adam/AdamW,
 --strict_nan_check (the reference's per-step host sync).
 """
 import torch
@@ -46,9 +47,11 @@ _ALIGN = 64     # floats: every parameter starts on a 256-byte boundary of the f
 
 
 class TrainEngine:
-    def __init__(self, model, optimizer, schedule, warmup_steps, total_steps, max_norm=1.0, use_graph=True):
-        """schedule: "linear" | "constant" (index/trainer.py:83-92) or None (fixed learning rate)."""
+    def __init__(self, model, optimizer, schedule, warmup_steps, total_steps, max_norm=1.0, use_graph=True, use_ema=False):
+        """schedule: "linear" | "constant" (index/trainer.py:83-92) or None (fixed learning rate).
+        use_ema: the improve fork's EMA codebook update after every step (index_improve/trainer.py:119)."""
         self.model = model
+        self.ema_levels = [q for q in model.rq.vq_layers if use_ema and q.ema_decay is not None]
         self.optimizer = optimizer
         self.max_norm = float(max_norm)
         self.use_graph = use_graph
@@ -81,8 +84,6 @@ class TrainEngine:
     def unsupported_reason(model, optimizer, args=None, dist=None, use_ema=False):
         if dist is not None:
             return "data-parallel run"
-        if use_ema:
-            return "EMA codebook update (index_improve)"
         if not isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
             return f"optimizer {type(optimizer).__name__}"
         if len(optimizer.param_groups) != 1 or optimizer.param_groups[0].get("amsgrad") or optimizer.param_groups[0].get("maximize"):
@@ -206,11 +207,21 @@ class TrainEngine:
         scale = 2.0 / (len(levels) * n * e)                                  # quantize.py: d mean-level-loss / d (sum of squares)
         gz = ops.quantizer_input_grad(z, cbs[0], q["idx"][:, 0], float(m.rq.beta) * scale, m.quant_loss_weight, g_xq)
         # per-code (count, sum) of every level and the codebook gradients (scale * (cnt*C - sum)) * g_loss: one launch
-        ops.code_stats_levels(q["idx"], q["resid_in"], [c.shape[0] for c in cbs], cbs,
-                              [self.grad_view[lvl.embedding.weight] for lvl in levels], scale, m.quant_loss_weight)
+        stats = ops.code_stats_levels(q["idx"], q["resid_in"], [c.shape[0] for c in cbs], cbs,
+                                      [self.grad_view[lvl.embedding.weight] for lvl in levels], scale, m.quant_loss_weight)
         self._mlp_backward(enc, gz, False, dw)
         ops.linear_backward_weights(dw)                                      # all 14 weight gradients, one launch
         del dw
+        # improve fork: EMA statistics and codebook blend (index_improve/models/vq.py:147-193).  The reference does this
+        # inside the forward; nothing between there and the optimizer reads the codebooks again (the gradients above were
+        # formed from the pre-update values, as autograd's saved tensors are), so here -- after them -- is equivalent.
+        for lvl in self.ema_levels:
+            t = levels.index(lvl)
+            if eager:
+                lvl.ema_step(stats[t], q["resid_in"][t])                    # counts the step, re-seeds dead codes when due
+            else:
+                ops.ema_update(lvl._ema_cluster_size, lvl._ema_w, lvl.embedding.weight.data, stats[t][0], stats[t][1],
+                               lvl.ema_decay, lvl.epsilon)
         ops.grad_norm_clip(self.flat_g, self.max_norm, out=self.clip)
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.base_lr, self.betas, self.eps,
                        self.weight_decay, self.decoupled, clip=self.clip, schedule=self.schedule,
@@ -223,15 +234,19 @@ class TrainEngine:
         """One training step on `batch` ([rows, in_dim] on the engine's device)."""
         rows = int(batch.shape[0])
         self.host_steps += 1
+        # a step on which a level's dead-code reset is due (host logic, random draws, data-dependent shapes) runs eagerly
+        reset_due = any((q.step_count + 1) % q.reset_interval == 0 for q in self.ema_levels)
         entry = self._graphs.get(rows)
-        if entry is not None:
+        if entry is not None and not reset_due:
             entry[1].copy_(batch)
             entry[0].replay()
             self.graph_replays += 1
+            for q in self.ema_levels:
+                q.step_count += 1
             return
         done = self._seen.get(rows, 0)
         lazy = any(not q.initted for q in self.model.rq.vq_layers)
-        if not self.use_graph or done < 1 or lazy:
+        if not self.use_graph or done < 1 or lazy or reset_due:
             # the first step at a batch size runs eagerly: it creates the stream's workspaces, runs the one-off k-means
             # initialisation (host sklearn), and it is a real training step
             with torch.no_grad(), ops.deferred_checks():
@@ -248,6 +263,8 @@ class TrainEngine:
         self._graphs[rows] = (graph, static)
         graph.replay()                                                       # capture records, replay executes: this step
         self.graph_replays += 1
+        for q in self.ema_levels:
+            q.step_count += 1
 
     def begin_epoch(self):
         self.sums.zero_()

@@ -184,7 +184,8 @@ class Trainer(object):
                 reason = "switched off (--train_engine off / LCREC_TRAIN_ENGINE=0)"
             if reason is None:
                 kind = "linear" if self.lr_scheduler_type.lower() == "linear" else "constant"
-                self.engine = TrainEngine(self.model, self.optimizer, kind, self.warmup_steps, self.max_steps)
+                self.engine = TrainEngine(self.model, self.optimizer, kind, self.warmup_steps, self.max_steps,
+                                          use_ema=self.use_ema)
                 self.logger.info("training step: one captured hipGraph per batch size (lcrec_amd.engine)")
             else:
                 self.logger.info("training step: autograd path (%s)", reason)

@@ -266,3 +266,42 @@ def test_trainer_uses_the_engine_and_matches_the_autograd_epochs(hip, tmp_path):
         assert torch.equal(v.cpu(), fresh.state_dict()[k]), k
     st = ck["optimizer"]["state"]
     assert len(st) == len(list(model.parameters())) and float(st[0]["step"]) == 12.0
+
+
+def test_engine_covers_the_ema_codebook_update(hip, tmp_path):
+    """index_improve's EMA path (use_ema): the captured step includes lcrec_ema_update; steps on which a dead-code reset
+    is due run eagerly.  Same epochs as the autograd path without resets; with resets the replay count shows which
+    steps left the graph."""
+    from lcrec_amd import main as cli
+    from lcrec_amd.datasets import DeviceLoader
+    from lcrec_amd.trainer import Trainer
+    data = torch.from_numpy(gi.toy_items(4, n=3000, d=128)).to(DEV)
+
+    def run(mode, reset_interval):
+        argv = ["--data_path", "unused", "--ckpt_dir", str(tmp_path / f"{mode}{reset_interval}"), "--device", DEV,
+                "--batch_size", "1000", "--epochs", "4", "--no_kmeans_init", "--num_emb_list", "32", "32", "--e_dim", "32",
+                "--layers", "64", "--sk_epsilons", "0.0", "0.0", "--train_engine", mode, "--no_bn", "--ema_decay", "0.9",
+                "--reset_interval", str(reset_interval), "--reset_threshold", "0.01", "--reset_seed", "5"]
+        args = cli.parse_args(argv)
+        cli.seed_everything(2024)
+        model = cli.build_model(args, 128)
+        for l, q in enumerate(model.rq.vq_layers):
+            q.reset_generator = torch.Generator(device=DEV).manual_seed(5 + l)
+        loader = DeviceLoader(data, 1000, True, DEV)
+        tr = Trainer(args, model, len(loader))
+        losses = [tr._train_epoch(loader, e) for e in range(4)]
+        return tr, losses
+
+    on, lo = run("auto", 10_000)
+    off, lf = run("off", 10_000)
+    assert on.engine is not None and on.engine.graph_replays == 12 - 1 and off.engine is None
+    np.testing.assert_allclose(np.array(lo), np.array(lf), rtol=5e-4)
+    for qa, qb in zip(on.model.rq.vq_layers, off.model.rq.vq_layers):
+        assert qa.step_count == qb.step_count == 12
+        np.testing.assert_allclose(qa._ema_cluster_size.cpu().numpy(), qb._ema_cluster_size.cpu().numpy(), rtol=2e-3, atol=1e-3)
+        np.testing.assert_allclose(qa._ema_w.cpu().numpy(), qb._ema_w.cpu().numpy(), rtol=5e-3, atol=5e-3)
+    # resets every 4th step: steps 4, 8, 12 run eagerly (and step 1): 12 - 4 replays; the run is reproducible
+    r1, l1 = run("auto", 4)
+    r2, l2 = run("auto", 4)
+    assert r1.engine.graph_replays == 12 - 4 and l1 == l2
+    assert all(torch.equal(a, b) for a, b in zip(r1.model.state_dict().values(), r2.model.state_dict().values()))
