@@ -305,3 +305,25 @@ def test_engine_covers_the_ema_codebook_update(hip, tmp_path):
     r2, l2 = run("auto", 4)
     assert r1.engine.graph_replays == 12 - 4 and l1 == l2
     assert all(torch.equal(a, b) for a, b in zip(r1.model.state_dict().values(), r2.model.state_dict().values()))
+
+
+def test_engine_small_batches_keep_the_sinkhorn_level_capturable(hip, tmp_path):
+    """Batches of <= 64 rows put the Sinkhorn level into the one-workgroup LDS class, whose group table must not travel by
+    a host copy inside a captured graph (it is a kernel argument for <= 4 groups): engine == autograd path at batch 48,
+    with BatchNorm, ragged last batch of 24 rows included."""
+    from lcrec_amd import main as cli
+    from lcrec_amd.datasets import DeviceLoader
+    from lcrec_amd.trainer import Trainer
+    data = torch.from_numpy(gi.toy_items(8, n=3000, d=128))[:600].to(DEV)
+    res = {}
+    for mode in ("auto", "off"):
+        argv = ["--data_path", "unused", "--ckpt_dir", str(tmp_path / mode), "--device", DEV, "--batch_size", "48", "--epochs", "2",
+                "--no_kmeans_init", "--num_emb_list", "64", "64", "--e_dim", "32", "--layers", "64", "--sk_epsilons", "0.0", "0.003",
+                "--train_engine", mode, "--bn", "True"]
+        args = cli.parse_args(argv)
+        cli.seed_everything(2024)
+        loader = DeviceLoader(data, 48, True, DEV)
+        tr = Trainer(args, cli.build_model(args, 128), len(loader))
+        res[mode] = (tr, [tr._train_epoch(loader, e) for e in range(2)])
+    assert res["auto"][0].engine.graph_replays == 2 * 13 - 2
+    np.testing.assert_allclose(np.array(res["auto"][1]), np.array(res["off"][1]), rtol=2e-3)
