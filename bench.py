@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="chunk pipelines of lcrec_encode_assign (lcrec_context_set_pipelines); 0 = the library's default (1)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="with --gpus 1: build a ONE-rank nccl (= RCCL) process group and run the N>1 code path through it "
+                         "(barriers, the MAX all-reduce of the time, the all-gather behind ranks_seen)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo = rehearsal of the N>1 code path, "
                          "ranks may then share one GPU")
@@ -187,9 +190,15 @@ def main():
         sys.exit(f"LOCAL_RANK {local_rank} but only {ndev} HIP device(s) visible")
     device = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or args.rehearse_rccl
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -213,7 +222,7 @@ def main():
         return ops.encode_assign(x, Ws, bs, flat, ks)[0]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -255,7 +264,7 @@ def main():
     del audit, idx_audit
     checksum = int(idx.sum())                        # per-rank: proves every rank computed, and what
     ranks_seen, checksums = 1, [checksum]
-    if world > 1:
+    if use_dist:
         cdev = device if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -375,7 +384,7 @@ def main():
                 sample = x[: min(n, 200_000)].cpu()
                 out["cpu_baseline"] = cpu_baseline(sample, dims, Ws, bs, cbs)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -233,14 +233,16 @@ def shard_range(n, rank, world_size):
     return lo, min(n, lo + per)
 
 
-def init_from_env(args=None, backend=None):
-    """Join the job torchrun started (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); single process otherwise."""
+def init_from_env(args=None, backend=None, force=False):
+    """Join the job torchrun started (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); single process otherwise.
+    force: build the process group even for WORLD_SIZE=1 (a one-rank RCCL group: every collective of the data-parallel
+    path then really goes through the backend -- how the one-GPU test box exercises RCCL)."""
     global _CTX
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not force:
         _CTX = DistContext(device=getattr(args, "device", None))
         return _CTX
-    rank = int(os.environ["RANK"])
+    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available() and (args is None or str(getattr(args, "device", "cuda")).startswith("cuda"))
     backend = backend or ("nccl" if use_gpu else "gloo")

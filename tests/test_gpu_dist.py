@@ -21,10 +21,10 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, tmp, ema, bn=False):
+def _run(rank, world, port, tmp, ema, bn=False, rccl=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    if world > 1:
+    if world > 1 or rccl:
         os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     else:
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -37,7 +37,8 @@ def _run(rank, world, port, tmp, ema, bn=False):
             "--sk_epsilons", "0.0", "0.0", "0.003", "--no_kmeans_init"] + (["--bn", "True"] if bn else ["--no_bn"]) \
         + (["--ema_decay", "0.95"] if ema else [])
     args = cli.parse_args(argv)
-    ctx = ldist.init_from_env(args, backend="gloo")
+    ctx = ldist.init_from_env(args, backend="nccl" if rccl else "gloo", force=rccl)
+    assert ctx.enabled == (world > 1 or rccl)
     cli.seed_everything(2024)
     model = cli.build_model(args, 48)
     g = torch.Generator().manual_seed(7)
@@ -50,7 +51,8 @@ def _run(rank, world, port, tmp, ema, bn=False):
     rate = trainer._valid_epoch(DeviceLoader(data, 96, False, "cuda:0", rank=ctx.rank, world_size=ctx.world_size))
     if ctx.rank == 0:
         sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-        np.savez(os.path.join(tmp, f"world{world}.npz"), losses=np.array(losses), rate=rate,
+        np.savez(os.path.join(tmp, f"world{world}{'rccl' if rccl else ''}.npz"), losses=np.array(losses), rate=rate,
+                 launched=np.int64(getattr(getattr(trainer, "grad_reducer", None), "launched", 0)),
                  ckpt_dirs=np.array(sorted(os.listdir(os.path.join(tmp, f"ck{world}")))), **sd)
     ldist.shutdown(ctx)
 
@@ -69,7 +71,7 @@ def test_two_ranks_reproduce_the_single_process_epoch(hip, tmp_path, ema, bn):
     assert float(two["rate"]) == pytest.approx(float(one["rate"]), abs=2e-2)
     worst = 0.0
     for k in one.files:
-        if k in ("losses", "rate", "ckpt_dirs"):
+        if k in ("losses", "rate", "ckpt_dirs", "launched"):
             continue
         a, b = one[k], two[k]
         assert a.shape == b.shape, k
@@ -140,3 +142,17 @@ def test_sharded_index_generation_writes_the_single_process_file(hip, tmp_path):
     assert np.array_equal(g1["history"], g2["history"]) and len(g1["history"]) >= 2 and int(g1["neartie"]) == int(g2["neartie"])
     # rank 0 of the two-rank run solved about half of the colliding rows of every round
     assert len(g1["rows"]) == len(g2["rows"]) and (g2["rows"] < 0.7 * g1["rows"]).all() and (g2["rows"] > 0.3 * g1["rows"]).all()
+
+
+def test_one_rank_rccl_group_runs_the_data_parallel_step(hip, tmp_path):
+    """RCCL cannot put two ranks on one GPU, but a ONE-rank "nccl" group is a real RCCL communicator: broadcast of the
+    initial weights, the bucketed asynchronous gradient all-reduce from backward hooks, the BatchNorm statistics exchange,
+    the Sinkhorn-level gather, the loss all-reduce and the evaluation gather all run through it -- and must leave the
+    single-process epoch (the engine's) unchanged."""
+    tmp = str(tmp_path)
+    mp.spawn(_run, args=(1, 0, tmp, False, True), nprocs=1, join=True)
+    mp.spawn(_run, args=(1, _free_port(), tmp, False, True, True), nprocs=1, join=True)
+    one, two = np.load(os.path.join(tmp, "world1.npz")), np.load(os.path.join(tmp, "world1rccl.npz"))
+    assert int(two["launched"]) > 0                    # buckets left from backward hooks, over RCCL
+    np.testing.assert_allclose(two["losses"], one["losses"], rtol=2e-4)
+    assert float(two["rate"]) == pytest.approx(float(one["rate"]), abs=2e-2)

@@ -156,3 +156,21 @@ def test_nan_loss_is_reported_with_and_without_the_per_step_sync(hip, tmp_path, 
         data[bad_batch * 64 + 5, 7] = float("nan")
         with pytest.raises(ValueError, match="Training loss is nan"):
             trainer._train_epoch(loader, 1)
+
+
+def test_bench_line_and_its_collective_path_over_a_one_rank_rccl_group(hip):
+    """bench.py end to end on a small shard: the JSON contract (metric, roofline, near-tie and rank fields) and -- with
+    --rehearse-rccl -- the N>1 code path (barrier, MAX all-reduce of the time, all-gather of the per-rank checksums) through
+    a real RCCL communicator of one rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--items", "150000", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--rehearse-rccl"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and len(line["idx_checksums"]) == 1
+    assert line["unit"] == "items/s" and line["value"] > 1e6 and line["scaling"] == "weak" and line["dtype"] == "f32"
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and 0.3 < r["frac"] < 1.0 and r["kernel"] == "linear_fwd_pp_256x128"
+    assert line["parity_mismatch_rows"] == 0 and 0 <= line["neartie_rows"] < 0.01 * 150000
