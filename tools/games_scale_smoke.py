@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--items", type=int, default=16859)
     ap.add_argument("--in_dim", type=int, default=4096)
     ap.add_argument("--kmeans_impl", default="sklearn")
+    ap.add_argument("--train_engine", default="auto", choices=["auto", "off"])
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
         rs = np.random.RandomState(0)
@@ -37,7 +38,7 @@ def main():
                                          "--batch_size", "1024", "--lr", "1e-3", "--weight_decay", "1e-4",
                                          "--num_emb_list", "256", "256", "256", "256", "--sk_epsilons", "0.0", "0.0", "0.0", "0.003",
                                          "--layers", "2048", "1024", "512", "256", "128", "64", "--e_dim", "32",
-                                         "--kmeans_impl", a.kmeans_impl])
+                                         "--kmeans_impl", a.kmeans_impl, "--bn", "False", "--train_engine", a.train_engine])    # run.sh:9: parses as True
         t1 = time.perf_counter()
         run = sorted(os.listdir(os.path.join(tmp, "ckpt")))[-1]
         ckpt = os.path.join(tmp, "ckpt", run, "best_collision_model.pth")
@@ -46,7 +47,7 @@ def main():
         t2 = time.perf_counter()
         index = json.load(open(out))
         steps = a.epochs * -(-a.items // 1024)
-        print(f"train {a.epochs} epochs ({steps} steps) incl. k-means init, 3 evals, checkpoints: {t1 - t0:.2f} s "
+        print(f"train {a.epochs} epochs ({steps} steps; index/run.sh flags incl. `--bn False` = BatchNorm ON) incl. k-means init, 3 evals, checkpoints: {t1 - t0:.2f} s "
               f"({(t1 - t0) / steps * 1e3:.2f} ms/step all-in); best loss {best_loss:.5f}, best collision rate {best_rate:.5f}")
         print(f"generate: {t2 - t1:.2f} s, rounds {stats['rounds']}, collision rate {stats['collision_rate']:.6f}, "
               f"max conflicts {stats['max_conflicts']}; json entries {len(index)}, first {index['0']}")
