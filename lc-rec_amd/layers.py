@@ -296,15 +296,18 @@ def kmeans(samples, num_clusters, num_iters=10):
 
 
 @torch.no_grad()
-def kmeans_pp_seed(x, num_clusters, generator=None):
-    """k-means++ seeding on the device: the first centre uniformly, every next one with probability
-    proportional to the squared distance to the nearest centre chosen so far (one draw per centre; sklearn's
-    greedy variant tries 2 + log K candidates per centre).  No host synchronisation: K draws are K queued launches.  All draws come from `generator` (a device
-    generator; default: one seeded from torch's global CPU generator, so torch.manual_seed governs it)."""
+def kmeans_pp_seed(x, num_clusters, generator=None, trials=None):
+    """Greedy k-means++ seeding on the device, as sklearn's _kmeans_plusplus does it: the first centre uniformly, every
+    next one the best of `trials` = 2 + floor(ln K) candidates drawn with probability proportional to the squared
+    distance to the nearest centre chosen so far -- best = smallest resulting potential.  All draws come from
+    `generator` (a device generator; default: one seeded from torch's global CPU generator, so torch.manual_seed governs
+    it).  No host synchronisation: K rounds of queued launches."""
+    import math
     n = x.shape[0]
     if generator is None:
         generator = torch.Generator(device=x.device)
         generator.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+    trials = int(trials) if trials else 2 + int(math.log(max(num_clusters, 1)))
     first = torch.randint(n, (1,), device=x.device, generator=generator)
     picks = [first]
     nearest = ((x - x[first]) ** 2).sum(1)
@@ -312,22 +315,25 @@ def kmeans_pp_seed(x, num_clusters, generator=None):
         w = nearest.clamp_min(0)
         # fewer distinct points than clusters: fall back to uniform -- decided on the device, no host round trip per centre
         w = torch.where(w.sum() > 0, w, torch.ones_like(w))
-        nxt = torch.multinomial(w, 1, generator=generator)
-        picks.append(nxt)
-        nearest = torch.minimum(nearest, ((x - x[nxt]) ** 2).sum(1))
+        cand = torch.multinomial(w, trials, replacement=True, generator=generator)            # [T]
+        d = torch.cdist(x, x[cand]) ** 2                                                       # [n, T]
+        pot = torch.minimum(nearest[:, None], d).sum(0)                                        # potential per candidate
+        best = pot.argmin()
+        picks.append(cand[best].reshape(1))
+        nearest = torch.minimum(nearest, d[:, best])
     return x[torch.cat(picks)].clone()
 
 
 @torch.no_grad()
-def kmeans_device(samples, num_clusters, num_iters=10, tol=1e-4, generator=None, init=None):
+def kmeans_device(samples, num_clusters, num_iters=10, tol=1e-4, generator=None, init=None, relocate_empty=True):
     """Device-resident replacement for the host sklearn call of layers.py:69-82 (SURVEY.md section 8f,
     rank 3): k-means++ seeding, then Lloyd iterations made of the library's own kernels --
     lcrec_rq_assign (one level) for the nearest centre and lcrec_code_stats for the per-cluster sums, both
     deterministic, so a run is reproducible bit for bit and equals oracle/cpu_oracle.kmeans_lloyd from the
     same seeds.  Stops after num_iters iterations or when the summed squared centre shift falls below
-    tol * mean feature variance (sklearn's rule).  An empty cluster keeps its centre (sklearn moves it to
-    a far point).  Not bit-comparable with sklearn -- nor is sklearn with itself across versions; the
-    reference's init is "parity unpinned" (SURVEY.md section 8c)."""
+    tol * mean feature variance (sklearn's rule).  An empty cluster's centre moves to a point far from its own centre, as
+    sklearn does (relocate_empty=False keeps it, which is what oracle/cpu_oracle.kmeans_lloyd restates).  Not
+    bit-comparable with sklearn -- nor is sklearn with itself across versions; the reference's init is "parity unpinned" (SURVEY.md section 8c)."""
     x = samples.detach().to(torch.float32).contiguous()
     if not x.is_cuda:
         raise ops._lib.LcrecError("kmeans_device expects a device tensor (lcrec_amd has no CPU path)")
@@ -335,9 +341,17 @@ def kmeans_device(samples, num_clusters, num_iters=10, tol=1e-4, generator=None,
                else init.detach().to(device=x.device, dtype=torch.float32).clone())
     limit = tol * x.var(dim=0, unbiased=False).mean()
     for _ in range(int(num_iters)):
-        idx = ops.rq_assign(x, centres.reshape(-1), [num_clusters])[0]
-        count, total = ops.code_stats(idx[:, 0], x, num_clusters)
+        res = ops.rq_assign(x, centres.reshape(-1), [num_clusters], want_xq=True)
+        nearest, x_q = res[0][:, 0], res[1]                 # x_q = r + (c - r): the assigned centre up to rounding
+        count, total = ops.code_stats(nearest, x, num_clusters)
         moved = torch.where(count[:, None] > 0, total / count[:, None].clamp_min(1.0), centres)
+        empty = count == 0
+        n_empty = int(empty.sum())                       # (the loop reads one scalar per iteration anyway: `shift` below)
+        if n_empty and relocate_empty:
+            # sklearn's rule (_relocate_empty_clusters_dense): an empty cluster's centre moves to one of the points farthest
+            # from the centre they are assigned to
+            far = ((x - x_q) ** 2).sum(1).topk(min(n_empty, x.shape[0])).indices
+            moved[torch.nonzero(empty).flatten()[: far.numel()]] = x[far]
         shift = ((moved - centres) ** 2).sum()
         centres = moved
         if bool(shift <= limit):

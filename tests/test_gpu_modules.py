@@ -132,7 +132,7 @@ def test_device_kmeans_matches_oracle_lloyd_and_is_reproducible(hip):
     x = gi.f32(blobs[rs.randint(0, 24, size=3000)] + 0.3 * rs.standard_normal((3000, 32)))
     xd = torch.from_numpy(x).to(DEV)
     init = x[rs.choice(3000, size=64, replace=False)]
-    got = layers.kmeans_device(xd, 64, num_iters=7, tol=0.0, init=torch.from_numpy(init))
+    got = layers.kmeans_device(xd, 64, num_iters=7, tol=0.0, init=torch.from_numpy(init), relocate_empty=False)
     want, iters = cpu_oracle.kmeans_lloyd(x, init, 7, tol=0.0)
     assert np.array_equal(got.cpu().numpy(), want)
 
@@ -146,6 +146,17 @@ def test_device_kmeans_matches_oracle_lloyd_and_is_reproducible(hip):
     assert torch.equal(c1, c2) and bool(torch.isfinite(c1).all())
     seed_only = layers.kmeans_pp_seed(xd, 24, torch.Generator(device=DEV).manual_seed(5))
     assert inertia(c1) <= inertia(seed_only) < inertia(xd[:24])
+    # quality against the reference's own initialiser on the F10 data (sklearn's centres are in the fixture): the device
+    # k-means++ / Lloyd run, empty clusters relocated as sklearn does, reaches a comparable inertia
+    g10 = np.load(os.path.join(GOLD, "f10_kmeans.npz"))
+    x10 = torch.from_numpy(gi.kmeans_case()).to(DEV)
+    for K, iters in ((256, 10), (64, 100)):
+        ref_c = torch.from_numpy(g10[f"centres_{K}_{iters}"]).to(DEV)
+        mine = layers.kmeans_device(x10, K, num_iters=iters, generator=torch.Generator(device=DEV).manual_seed(1))
+        i_ref = float(torch.cdist(x10, ref_c).min(1).values.pow(2).sum())
+        i_mine = float(torch.cdist(x10, mine).min(1).values.pow(2).sum())
+        assert i_mine <= 1.10 * i_ref, (K, i_mine, i_ref)
+        assert int((hip.ops.code_stats(hip.ops.rq_assign(x10, mine.reshape(-1), [K])[0][:, 0], x10, K)[0] == 0).sum()) <= K // 50
     # same entry point the quantiser calls when main.py is given --kmeans_impl device
     layers.KMEANS_IMPL = "device"
     try:
