@@ -288,15 +288,22 @@ int lcrec_bn_relu_backward(const float *gy, const float *t, const float *y, int6
 /* The same two operations split where an item-sharded (data-parallel) run exchanges statistics, so that the batch is the
  * union of all ranks' rows (torch.nn.SyncBatchNorm semantics; the reference's index/ stage is single-process, SURVEY.md
  * section 8e item 4):
- *   lcrec_bn_stats            local mean and M2 = sum (t - mean)^2 of this rank's n rows      -> merged over ranks by the caller
+ *   lcrec_bn_stats            local mean and M2 = sum (t - mean)^2 of this rank's n rows      -> exchanged by the caller
+ *   lcrec_bn_merge_stats      rows[world][2*features+1] = every rank's (n_r, mean_r[], M2_r[]) -> mean, rstd of the union of
+ *                             the rows (Chan et al., merged in rank order: the same bits on every rank) and the running
+ *                             statistics as nn.BatchNorm1d keeps them (running_* may be NULL)
  *   lcrec_bn_relu_apply       y = [relu]((t - mean) * rstd * gamma + beta) with the merged statistics
- *   lcrec_bn_backward_reduce  local sum g and sum g*xhat (g = gy * [y > 0])                    -> all-reduced by the caller
+ *   lcrec_bn_backward_reduce  local sum g and sum g*xhat (g = gy * [y > 0])                    -> all-reduced by the caller;
+ *                             dbeta_out / dgamma_out (may be NULL) receive a copy: this rank's share of the parameter gradients
  *   lcrec_bn_backward_apply   dt = gamma*rstd*(g - sum_g/n_total - xhat*sum_gx/n_total), dbias = local column sums of dt */
 int lcrec_bn_stats(const float *t, int64_t n, int features, float *mean_out, float *m2_out, void *stream);
+int lcrec_bn_merge_stats(const float *rows, int world, int features, float eps, float momentum, float *mean_out, float *rstd_out,
+                         float *running_mean, float *running_var, void *stream);
 int lcrec_bn_relu_apply(const float *t, int64_t n, int features, const float *gamma, const float *beta, const float *mean,
                         const float *rstd, int relu, float *y, void *stream);
 int lcrec_bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int features, const float *mean,
-                             const float *rstd, int relu, float *sum_g_out, float *sum_gx_out, void *stream);
+                             const float *rstd, int relu, float *sum_g_out, float *sum_gx_out, float *dbeta_out,
+                             float *dgamma_out, void *stream);
 int lcrec_bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
                             const float *mean, const float *rstd, int relu, const float *sum_g, const float *sum_gx,
                             float n_total, float *dt_out, float *dbias_out, void *stream);
@@ -311,9 +318,12 @@ size_t lcrec_train_reduce_workspace(void);
 
 /* Reconstruction loss and its gradient, index/models/rqvae.py:74-85: l1 == 0: loss = mean (out-x)^2,
  * grad = 2 (out-x)/count; l1 != 0: loss = mean |out-x|, grad = sign(out-x)/count.  count = n * in_dim elements;
- * loss_out is a device float (fp64 accumulation); grad_out [count] or NULL. */
-int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *grad_out, float *loss_out,
-                          void *workspace, size_t workspace_bytes, void *stream);
+ * loss_out is a device float (fp64 accumulation); grad_out [count] or NULL.
+ * count_total (0 = count): the element count of the GLOBAL batch when these `count` elements are one rank's shard of
+ * it (item-sharded data parallel): both divisions use count_total, so loss_out is this rank's share of the global
+ * mean and the ranks' gradients sum to the global-batch gradient. */
+int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *grad_out,
+                          float *loss_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (index/trainer.py:118) on a flat gradient buffer:
  * norm_out[0] = ||grads||_2 (fp64 accumulation), norm_out[1] = min(1, max_norm / (norm + 1e-6)), the coefficient

@@ -66,12 +66,14 @@ _SIGNATURES = {
                                               _vp, _vp, _vp, _vp]),
     "lcrec_bn_stats": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp]),
     "lcrec_bn_relu_apply": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
-    "lcrec_bn_backward_reduce": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "lcrec_bn_backward_reduce": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp,
+                                                _vp]),
+    "lcrec_bn_merge_stats": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     "lcrec_bn_backward_apply": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _vp, _vp,
                                                ctypes.c_float, _vp, _vp, _vp]),
     "lcrec_relu_bias_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "lcrec_train_reduce_workspace": (ctypes.c_size_t, []),
-    "lcrec_recon_loss_grad": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_recon_loss_grad": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_grad_norm_clip": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
     "lcrec_codebook_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "lcrec_step_losses": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp,

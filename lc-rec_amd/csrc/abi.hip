@@ -393,10 +393,10 @@ LCREC_API int lcrec_relu_bias_backward(const float *gy, const float *y, int64_t 
 
 LCREC_API size_t lcrec_train_reduce_workspace(void) { return train_reduce_workspace(); }
 
-LCREC_API int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *grad_out, float *loss_out,
-                                    void *workspace, size_t workspace_bytes, void *stream)
+LCREC_API int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *grad_out,
+                                    float *loss_out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return recon_loss_grad(out, x, count, l1, grad_out, loss_out, workspace, workspace_bytes, (hipStream_t)stream);
+    return recon_loss_grad(out, x, count, count_total, l1, grad_out, loss_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_grad_norm_clip(const float *grads, int64_t count, float max_norm, float *norm_out, void *workspace,
@@ -432,9 +432,16 @@ LCREC_API int lcrec_bn_relu_apply(const float *t, int64_t n, int features, const
 }
 
 LCREC_API int lcrec_bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int features, const float *mean,
-                                       const float *rstd, int relu, float *sum_g_out, float *sum_gx_out, void *stream)
+                                       const float *rstd, int relu, float *sum_g_out, float *sum_gx_out, float *dbeta_out,
+                                       float *dgamma_out, void *stream)
 {
-    return bn_backward_reduce(gy, t, y, n, features, mean, rstd, relu, sum_g_out, sum_gx_out, (hipStream_t)stream);
+    return bn_backward_reduce(gy, t, y, n, features, mean, rstd, relu, sum_g_out, sum_gx_out, dbeta_out, dgamma_out, (hipStream_t)stream);
+}
+
+LCREC_API int lcrec_bn_merge_stats(const float *rows, int world, int features, float eps, float momentum, float *mean_out,
+                                   float *rstd_out, float *running_mean, float *running_var, void *stream)
+{
+    return bn_merge_stats(rows, world, features, eps, momentum, mean_out, rstd_out, running_mean, running_var, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,

@@ -143,17 +143,19 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
 int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
                      const float *rstd, int relu, float *dt, float *dgamma, float *dbeta, float *dbias, hipStream_t stream);
 int bn_stats(const float *t, int64_t n, int F, float *mean_out, float *m2_out, hipStream_t stream);
+int bn_merge_stats(const float *rows, int world, int F, float eps, float momentum, float *mean_out, float *rstd_out,
+                   float *running_mean, float *running_var, hipStream_t stream);
 int bn_relu_apply(const float *t, int64_t n, int F, const float *gamma, const float *beta, const float *mean, const float *rstd,
                   int relu, float *y, hipStream_t stream);
 int bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int F, const float *mean, const float *rstd,
-                       int relu, float *sum_g, float *sum_gx, hipStream_t stream);
+                       int relu, float *sum_g, float *sum_gx, float *dbeta, float *dgamma, hipStream_t stream);
 int bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
                       const float *rstd, int relu, const float *sum_g, const float *sum_gx, float n_total, float *dt, float *dbias,
                       hipStream_t stream);
 int relu_bias_backward(const float *gy, const float *y, int64_t n, int F, int relu, float *g_out, float *dbias, hipStream_t stream);
 size_t train_reduce_workspace();
-int recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *g, float *loss, void *workspace,
-                    size_t workspace_bytes, hipStream_t stream);
+int recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *g, float *loss,
+                    void *workspace, size_t workspace_bytes, hipStream_t stream);
 int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_out, void *workspace, size_t workspace_bytes,
                    hipStream_t stream);
 int step_losses(const double *sse, int L, int64_t n, int e, float beta, float qlw, const float *recon, float *out3, double *sums2,

@@ -259,6 +259,34 @@ __global__ __launch_bounds__(CR_THREADS) void bn_stats_kernel(const float *__res
     if (st.live && st.rg == 0) { mean_out[col] = pivot + dmean; m2_out[col] = m2; }
 }
 
+// Statistics of the union of the ranks' rows from their (n_r, mean_r[F], M2_r[F]) rows (Chan et al., merged in rank order so
+// every rank computes the same bits): mean = sum n_r mean_r / N, M2 = sum (M2_r + n_r (mean_r - mean)^2); rstd and the
+// running statistics as nn.BatchNorm1d keeps them (biased variance normalises, unbiased goes into running_var).
+__global__ __launch_bounds__(256) void bn_merge_stats_kernel(const float *__restrict__ rows, int world, int F, float eps, float momentum,
+                                                             float *mean_out, float *rstd_out, float *running_mean, float *running_var)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= F) return;
+    const int64_t stride = 2 * (int64_t)F + 1;
+    float total = 0.f, acc = 0.f;
+    for (int r = 0; r < world; ++r) {
+        const float nr = rows[r * stride];
+        total += nr;
+        acc += nr * rows[r * stride + 1 + col];
+    }
+    const float mean = acc / total;
+    float m2 = 0.f;
+    for (int r = 0; r < world; ++r) {
+        const float nr = rows[r * stride];
+        const float d = rows[r * stride + 1 + col] - mean;
+        m2 += rows[r * stride + 1 + F + col] + nr * (d * d);
+    }
+    mean_out[col] = mean;
+    rstd_out[col] = 1.0f / __builtin_sqrtf(m2 / total + eps);
+    if (running_mean) running_mean[col] = (1.0f - momentum) * running_mean[col] + momentum * mean;
+    if (running_var) running_var[col] = (1.0f - momentum) * running_var[col] + momentum * (m2 / (total > 1.f ? total - 1.f : 1.f));
+}
+
 // y = [relu]((t - mean) * rstd * gamma + beta) with given (global) statistics
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float *__restrict__ t, int64_t n, int F, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, const float *__restrict__ mean,
@@ -278,7 +306,7 @@ template <int COLS>
 __global__ __launch_bounds__(CR_THREADS) void bn_backward_reduce_kernel(const float *__restrict__ gy, const float *__restrict__ t,
                                                                         const float *__restrict__ y, int64_t n, int F,
                                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
-                                                                        int relu, float *sum_g, float *sum_gx)
+                                                                        int relu, float *sum_g, float *sum_gx, float *dbeta, float *dgamma)
 {
     __shared__ float sm[CR_WAVES][COLS];
     const Strip<COLS> st(F);
@@ -294,7 +322,11 @@ __global__ __launch_bounds__(CR_THREADS) void bn_backward_reduce_kernel(const fl
     });
     db = st.sum(db, sm);
     dg = st.sum(dg, sm);
-    if (st.live && st.rg == 0) { sum_g[col] = db; sum_gx[col] = dg; }
+    if (st.live && st.rg == 0) {
+        sum_g[col] = db; sum_gx[col] = dg;
+        if (dbeta) dbeta[col] = db;          // this rank's share of the parameter gradients (the gradient all-reduce sums them)
+        if (dgamma) dgamma[col] = dg;
+    }
 }
 
 // dt = gamma * rstd * (g - sum_g / n_total - xhat * sum_gx / n_total) with the GLOBAL sums; dbias = local column sums of dt
@@ -369,10 +401,11 @@ __device__ __forceinline__ double block_sum(double v, double *sm)
 
 // mse: loss = mean (out - x)^2, g = 2 (out - x) / count;  l1: loss = mean |out - x|, g = sign(out - x) / count
 __global__ __launch_bounds__(RED_THREADS) void recon_loss_grad_kernel(const float *__restrict__ out, const float *__restrict__ x,
-                                                                       int64_t count, int l1, float *__restrict__ g, double *partial)
+                                                                       int64_t count, int64_t count_total, int l1,
+                                                                       float *__restrict__ g, double *partial)
 {
     __shared__ double sm[RED_THREADS / 64];
-    const float scale = (l1 ? 1.0f : 2.0f) / (float)count;
+    const float scale = (l1 ? 1.0f : 2.0f) / (float)count_total;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < count; i += (int64_t)gridDim.x * RED_THREADS) {
         const float d = out[i] - x[i];
@@ -606,6 +639,17 @@ int bn_stats(const float *t, int64_t n, int F, float *mean_out, float *m2_out, h
     return check_launch("bn_stats_kernel");
 }
 
+int bn_merge_stats(const float *rows, int world, int F, float eps, float momentum, float *mean_out, float *rstd_out,
+                   float *running_mean, float *running_var, hipStream_t stream)
+{
+    if (!rows || !mean_out || !rstd_out) return fail(LCREC_EINVAL, "bn_merge_stats: NULL pointer");
+    if (world < 1 || world > 4096 || F < 1) return fail(LCREC_EINVAL, "bn_merge_stats: bad shape (world=%d, features=%d)", world, F);
+    TraceScope trace(K_BN_FWD, stream);
+    hipLaunchKernelGGL(bn_merge_stats_kernel, dim3((F + 255) / 256), dim3(256), 0, stream, rows, world, F, eps, momentum, mean_out,
+                       rstd_out, running_mean, running_var);
+    return check_launch("bn_merge_stats_kernel");
+}
+
 int bn_relu_apply(const float *t, int64_t n, int F, const float *gamma, const float *beta, const float *mean, const float *rstd,
                   int relu, float *y, hipStream_t stream)
 {
@@ -619,12 +663,12 @@ int bn_relu_apply(const float *t, int64_t n, int F, const float *gamma, const fl
 }
 
 int bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t n, int F, const float *mean, const float *rstd,
-                       int relu, float *sum_g, float *sum_gx, hipStream_t stream)
+                       int relu, float *sum_g, float *sum_gx, float *dbeta, float *dgamma, hipStream_t stream)
 {
     if (!gy || !t || !mean || !rstd || !sum_g || !sum_gx || (relu && !y)) return fail(LCREC_EINVAL, "bn_backward_reduce: NULL pointer");
     if (n < 1 || n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_backward_reduce: sized for training batches");
     TraceScope trace(K_BN_BWD, stream);
-    LCREC_STRIP_LAUNCH(bn_backward_reduce_kernel, F, stream, gy, t, y, n, F, mean, rstd, relu, sum_g, sum_gx);
+    LCREC_STRIP_LAUNCH(bn_backward_reduce_kernel, F, stream, gy, t, y, n, F, mean, rstd, relu, sum_g, sum_gx, dbeta, dgamma);
     return check_launch("bn_backward_reduce_kernel");
 }
 
@@ -657,16 +701,18 @@ static int red_blocks(int64_t count)
 
 size_t train_reduce_workspace() { return RED_MAX_BLOCKS * sizeof(double); }
 
-int recon_loss_grad(const float *out, const float *x, int64_t count, int l1, float *g, float *loss, void *workspace,
-                    size_t workspace_bytes, hipStream_t stream)
+int recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *g, float *loss,
+                    void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
+    if (count_total == 0) count_total = count;
+    if (count_total < count) return fail(LCREC_EINVAL, "recon_loss_grad: count_total < count");
     if (!out || !x || !loss) return fail(LCREC_EINVAL, "recon_loss_grad: NULL pointer");
     if (count < 1) return fail(LCREC_EINVAL, "recon_loss_grad: empty input");
     if (!workspace || workspace_bytes < train_reduce_workspace()) return fail(LCREC_EWORKSPACE, "recon_loss_grad: workspace too small");
     const int blocks = red_blocks(count);
     TraceScope trace(K_LOSS, stream);
-    hipLaunchKernelGGL(recon_loss_grad_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, out, x, count, l1, g, (double *)workspace);
-    hipLaunchKernelGGL(recon_loss_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, count, loss);
+    hipLaunchKernelGGL(recon_loss_grad_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, out, x, count, count_total, l1, g, (double *)workspace);
+    hipLaunchKernelGGL(recon_loss_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, count_total, loss);
     return check_launch("recon_loss_grad_kernel");
 }
 

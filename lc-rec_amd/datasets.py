@@ -104,7 +104,7 @@ class DeviceLoader:
             self.last_global_rows = hi - lo
             if self.world_size > 1:
                 # item-sharded data parallel: every rank walks the same global batch and keeps its slice
-                m = batch.shape[0]
-                per = (m + self.world_size - 1) // self.world_size
-                batch = batch[self.rank * per:min(m, (self.rank + 1) * per)]
+                from .dist import batch_slice
+                a, b = batch_slice(batch.shape[0], self.rank, self.world_size)
+                batch = batch[a:b]
             yield batch

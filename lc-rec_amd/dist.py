@@ -67,6 +67,28 @@ class DistContext:
         """Rows of this rank / of all ranks in the current training batch (the loader knows both without a collective)."""
         self.batch_rows = (int(n_local), int(n_global))
 
+    def row_counts(self, n_local):
+        """Rows of every rank in the current batch: from set_batch (the loader's split, no collective) when it describes
+        this tensor, else by an all-reduce."""
+        rows = getattr(self, "batch_rows", None)
+        if rows is not None and rows[0] == n_local:
+            counts = batch_counts(rows[1], self.world_size)
+            if counts[self.rank] == n_local:
+                return counts
+        return None
+
+    def exchange_rows(self, row):
+        """[world, len(row)]: every rank's copy of a small 1-d float tensor, in rank order -- ONE collective (all-gather
+        over RCCL; gloo has none for device tensors, so there a zero-padded all-reduce does the same)."""
+        if tdist.get_backend() == "gloo":
+            buf = torch.zeros((self.world_size, row.numel()), dtype=row.dtype, device=row.device)
+            buf[self.rank].copy_(row)
+            tdist.all_reduce(buf, op=tdist.ReduceOp.SUM)
+            return buf
+        out = torch.empty((self.world_size, row.numel()), dtype=row.dtype, device=row.device)
+        tdist.all_gather_into_tensor(out.view(-1), row.contiguous())
+        return out
+
     def merge_batch_stats(self, n_local, mean, m2):
         """Per-rank BatchNorm statistics -> (mean, M2, n) of the global batch: every rank puts (n_r, mean_r, M2_r) into its
         row of a [world, 2F+1] buffer, ONE all-reduce makes all rows visible everywhere, and the rows are merged by
@@ -102,8 +124,17 @@ class DistContext:
         # gloo (the CPU rehearsal backend) has no all_gather for device tensors: stage through the host there
         via_host = rows.is_cuda and tdist.get_backend() == "gloo"
         work = torch.device("cpu") if via_host else rows.device
-        pad = torch.zeros((width,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=work)
-        pad[:rows.shape[0]] = rows
+        if rows.shape[0] == width:
+            pad = rows.contiguous().to(work)
+        else:
+            pad = torch.zeros((width,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=work)
+            pad[:rows.shape[0]] = rows
+        if not via_host and tdist.get_backend() != "gloo":
+            flat = torch.empty((self.world_size * width,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=work)
+            tdist.all_gather_into_tensor(flat, pad)                  # one collective, no per-rank output tensors
+            if min(counts) == width:
+                return flat
+            return torch.cat([flat[r * width:r * width + c] for r, c in enumerate(counts)])
         out = [torch.empty_like(pad) for _ in range(self.world_size)]
         tdist.all_gather(out, pad)
         return torch.cat([o[:c] for o, c in zip(out, counts)]).to(rows.device)
@@ -112,8 +143,8 @@ class DistContext:
         """(all rows in rank order, (lo, hi) of this rank's rows inside them)."""
         if not self.enabled:
             return rows, (0, rows.shape[0])
-        counts = self._row_counts(rows.shape[0], rows.device)
-        allrows = self.gather_rows(rows)
+        counts = self.row_counts(rows.shape[0]) or self._row_counts(rows.shape[0], rows.device)
+        allrows = self.gather_rows(rows, counts)
         lo = sum(counts[:self.rank])
         return allrows, (lo, lo + counts[self.rank])
 
@@ -146,6 +177,12 @@ class DistContext:
             k = t.numel()
             t.copy_(flat[off:off + k].view_as(t))
             off += k
+
+    def all_reduce_(self, tensor, async_op=False):
+        """In-place SUM over the ranks of one contiguous tensor; the work handle when async_op."""
+        if self.enabled:
+            return tdist.all_reduce(tensor, op=tdist.ReduceOp.SUM, async_op=async_op)
+        return None
 
     def broadcast_(self, tensor, src=0):
         if self.enabled:
@@ -226,6 +263,19 @@ def current():
     return _CTX
 
 
+def batch_counts(m, world_size):
+    """Rows per rank when a batch of m rows is dealt to the ranks as evenly as contiguous slices allow: the first m % W
+    ranks hold one row more (DeviceLoader; 475 rows on 8 ranks = 60,60,60,59,59,59,59,59)."""
+    base, extra = divmod(int(m), int(world_size))
+    return [base + (1 if r < extra else 0) for r in range(world_size)]
+
+
+def batch_slice(m, rank, world_size):
+    counts = batch_counts(m, world_size)
+    lo = sum(counts[:rank])
+    return lo, lo + counts[rank]
+
+
 def shard_range(n, rank, world_size):
     """Contiguous item range of `rank` when n items are split over world_size ranks."""
     per = (n + world_size - 1) // world_size
@@ -280,7 +330,8 @@ def attach(trainer, ctx):
         except OSError:
             pass
     trainer.ckpt_dir = names[0]
-    trainer.grad_reducer = GradReducer(ctx, list(model.parameters()))
+    # the gradient exchange belongs to whichever step implementation the trainer picks in its first epoch: the captured
+    # engine all-reduces its own flat buffer (engine.py); the autograd path builds a GradReducer then (Trainer._reducer)
     return trainer
 
 

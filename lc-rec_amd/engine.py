@@ -47,10 +47,17 @@ _ALIGN = 64     # floats: every parameter starts on a 256-byte boundary of the f
 
 
 class TrainEngine:
-    def __init__(self, model, optimizer, schedule, warmup_steps, total_steps, max_norm=1.0, use_graph=True, use_ema=False):
+    def __init__(self, model, optimizer, schedule, warmup_steps, total_steps, max_norm=1.0, use_graph=True, use_ema=False,
+                 dist=None):
         """schedule: "linear" | "constant" (index/trainer.py:83-92) or None (fixed learning rate).
-        use_ema: the improve fork's EMA codebook update after every step (index_improve/trainer.py:119)."""
+        use_ema: the improve fork's EMA codebook update after every step (index_improve/trainer.py:119).
+        dist: an enabled dist.DistContext for item-sharded data parallel (the caller sets dist.set_batch before a step)."""
         self.model = model
+        self.dist = dist if (dist is not None and dist.enabled) else None
+        if self.dist is not None:
+            import torch.distributed as tdist
+            use_graph = use_graph and tdist.get_backend() == "nccl"      # gloo collectives synchronise the host
+        self.collectives = 0                                                 # collectives issued or captured (tests, logs)
         self.ema_levels = [q for q in model.rq.vq_layers if use_ema and q.ema_decay is not None]
         self.optimizer = optimizer
         self.max_norm = float(max_norm)
@@ -82,8 +89,6 @@ class TrainEngine:
     # ------------------------------------------------------------------ support matrix
     @staticmethod
     def unsupported_reason(model, optimizer, args=None, dist=None, use_ema=False):
-        if dist is not None:
-            return "data-parallel run"
         if not isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
             return f"optimizer {type(optimizer).__name__}"
         if len(optimizer.param_groups) != 1 or optimizer.param_groups[0].get("amsgrad") or optimizer.param_groups[0].get("maximize"):
@@ -125,6 +130,17 @@ class TrainEngine:
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self._step_f32 = torch.zeros((), dtype=torch.float32, device=dev)
         self.grad_view = {}
+        # spans of the flat buffers for the data-parallel gradient exchange: the decoder's parameters (contiguous in
+        # parameter order) and whatever lies before / after them
+        dec = {id(p) for p in self.model.decoder.parameters()}
+        where = [i for i, p in enumerate(self.params) if id(p) in dec]
+        if where and where == list(range(where[0], where[-1] + 1)):
+            lo = offs[where[0]]
+            hi = offs[where[-1] + 1] if where[-1] + 1 < len(offs) else total
+            self._late_span = (lo, hi)
+            self._early_spans = [(a, b) for a, b in ((0, lo), (hi, total)) if b > a]
+        else:
+            self._late_span, self._early_spans = None, [(0, total)]
         with torch.no_grad():
             for p, off in zip(self.params, offs):
                 n = p.numel()
@@ -152,8 +168,14 @@ class TrainEngine:
             if "bn" in g:
                 bn = mods[g["bn"]]
                 t = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=False)
-                y, mean, rstd = ops.bn_relu_forward(t, bn.weight.data, bn.bias.data, bn.eps, bn.momentum, bn.running_mean,
-                                                    bn.running_var, relu=relu)
+                if self.dist is not None:
+                    from .layers import sharded_bn_statistics
+                    mean, rstd, _ = sharded_bn_statistics(self.dist, t, bn)          # statistics of the GLOBAL batch
+                    y = ops.bn_relu_apply(t, bn.weight.data, bn.bias.data, mean, rstd, relu)
+                    self.collectives += 1
+                else:
+                    y, mean, rstd = ops.bn_relu_forward(t, bn.weight.data, bn.bias.data, bn.eps, bn.momentum, bn.running_mean,
+                                                        bn.running_var, relu=relu)
                 saved.append((h, lin, bn, relu, t, y, mean, rstd))
             else:
                 y = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=relu)
@@ -168,7 +190,13 @@ class TrainEngine:
         gv = self.grad_view
         for i in range(len(saved) - 1, -1, -1):
             h, lin, bn, relu, t, y, mean, rstd = saved[i]
-            if bn is not None:
+            if bn is not None and self.dist is not None:
+                sums = ops.bn_backward_reduce(g, t, y, mean, rstd, relu, dbeta_out=gv[bn.bias], dgamma_out=gv[bn.weight])
+                self.dist.all_reduce_(sums)
+                self.collectives += 1
+                dt, _ = ops.bn_backward_apply(g, t, y, bn.weight.data, mean, rstd, sums, self.dist.batch_rows[1], relu,
+                                              dbias_out=gv[lin.bias])
+            elif bn is not None:
                 dt, _, _, _ = ops.bn_relu_backward(g, t, y, bn.weight.data, mean, rstd, relu, dgamma_out=gv[bn.weight],
                                                    dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias])
             else:
@@ -198,12 +226,30 @@ class TrainEngine:
         counters = [s[2].num_batches_tracked for s in enc + dec if s[2] is not None]
         if counters:
             torch._foreach_add_(counters, 1)                                 # BatchNorm1d.num_batches_tracked, all layers at once
-        recon, g_out = ops.recon_loss_grad(out, x, m.loss_type)
+        world = self.dist
         n, e = z.shape
+        works = []
+        if world is None:
+            recon, g_out = ops.recon_loss_grad(out, x, m.loss_type)
+            sse = q["sse"]
+        else:
+            # this rank's share of the global-batch losses; one all-reduce of L+1 doubles makes them the global ones
+            n = world.batch_rows[1]
+            share, g_out = ops.recon_loss_grad(out, x, m.loss_type, global_rows=n)
+            both = torch.cat([q["sse"], share.double().reshape(1)])
+            world.all_reduce_(both)
+            self.collectives += 1
+            sse, recon = both[:len(levels)], both[len(levels)].float()
         # level losses, their mean, the total loss, the epoch's running sums and the NaN flag: one launch
-        ops.step_losses(q["sse"], n, e, float(m.rq.beta), m.quant_loss_weight, recon, self.last, self.sums, self.bad[0])
+        ops.step_losses(sse, n, e, float(m.rq.beta), m.quant_loss_weight, recon, self.last, self.sums, self.bad[0])
         dw = []
         g_xq = self._mlp_backward(dec, g_out, True, dw)
+        if world is not None and self._late_span is not None:
+            ops.linear_backward_weights(dw)                                  # the decoder's weight gradients, one launch ...
+            dw = []
+            lo, hi = self._late_span                                         # ... and its span of the flat buffer is on its way
+            works.append(world.all_reduce_(self.flat_g[lo:hi], async_op=True))
+            self.collectives += 1
         scale = 2.0 / (len(levels) * n * e)                                  # quantize.py: d mean-level-loss / d (sum of squares)
         gz = ops.quantizer_input_grad(z, cbs[0], q["idx"][:, 0], float(m.rq.beta) * scale, m.quant_loss_weight, g_xq)
         # per-code (count, sum) of every level and the codebook gradients (scale * (cnt*C - sum)) * g_loss: one launch
@@ -212,6 +258,17 @@ class TrainEngine:
         self._mlp_backward(enc, gz, False, dw)
         ops.linear_backward_weights(dw)                                      # all 14 weight gradients, one launch
         del dw
+        if world is not None:
+            for lo, hi in self._early_spans:
+                works.append(world.all_reduce_(self.flat_g[lo:hi], async_op=True))
+                self.collectives += 1
+            if not eager:
+                for lvl in self.ema_levels:                                  # (eager: VectorQuantizer.ema_step does it)
+                    for stat in stats[levels.index(lvl)]:
+                        world.all_reduce_(stat)
+                        self.collectives += 1
+            for w in works:
+                w.wait()
         # improve fork: EMA statistics and codebook blend (index_improve/models/vq.py:147-193).  The reference does this
         # inside the forward; nothing between there and the optimizer reads the codebooks again (the gradients above were
         # formed from the pre-update values, as autograd's saved tensors are), so here -- after them -- is equivalent.
@@ -233,6 +290,11 @@ class TrainEngine:
     def step(self, batch):
         """One training step on `batch` ([rows, in_dim] on the engine's device)."""
         rows = int(batch.shape[0])
+        if self.dist is not None:
+            held = getattr(self.dist, "batch_rows", None)
+            if held is None or held[0] != rows:
+                raise ops._lib.LcrecError("data-parallel step: call dist.set_batch(local rows, global rows) first")
+            rows = (rows, held[1])                                           # a graph per (local, global) batch shape
         self.host_steps += 1
         # a step on which a level's dead-code reset is due (host logic, random draws, data-dependent shapes) runs eagerly
         reset_due = any((q.step_count + 1) % q.reset_interval == 0 for q in self.ema_levels)
@@ -257,9 +319,22 @@ class TrainEngine:
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.no_grad(), ops.deferred_checks():
-            with torch.cuda.graph(graph, stream=side):
-                self._run(static, eager=False)
+        try:
+            with torch.no_grad(), ops.deferred_checks():
+                with torch.cuda.graph(graph, stream=side):
+                    self._run(static, eager=False)
+        except RuntimeError as err:
+            if self.dist is None:
+                raise
+            # a collective backend that cannot be captured: keep the straight line, launched eagerly (every rank runs the
+            # same library build, so every rank ends up here)
+            import logging
+            logging.getLogger().warning("lcrec_amd.engine: data-parallel step not capturable (%s); running it eagerly", err)
+            self.use_graph = False
+            torch.cuda.synchronize(self.device)
+            with torch.no_grad(), ops.deferred_checks():
+                self._run(batch.contiguous(), eager=True)
+            return
         self._graphs[rows] = (graph, static)
         graph.replay()                                                       # capture records, replay executes: this step
         self.graph_replays += 1

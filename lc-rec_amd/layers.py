@@ -33,14 +33,8 @@ class _BatchNormAct(torch.autograd.Function):
         world = ldist.current()
         n_local = t.shape[0]
         if world.enabled:
-            mean_l, m2_l = ops.bn_stats(t)
-            mean, m2, n_total = world.merge_batch_stats(n_local, mean_l, m2_l)
-            rstd = torch.rsqrt(m2 / n_total + bn.eps)
+            mean, rstd, n_total = sharded_bn_statistics(world, t, bn)
             y = ops.bn_relu_apply(t, gamma.detach(), beta.detach(), mean, rstd, relu)
-            with torch.no_grad():
-                mom = bn.momentum
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(m2 / max(n_total - 1, 1), alpha=mom)
         else:
             n_total = n_local
             y, mean, rstd = ops.bn_relu_forward(t, gamma.detach(), beta.detach(), bn.eps, bn.momentum, bn.running_mean,
@@ -58,11 +52,26 @@ class _BatchNormAct(torch.autograd.Function):
             world = ldist.current()
             local = ops.bn_backward_reduce(gy, t, y, mean, rstd, ctx.relu)
             total = local.clone()
-            world.all_reduce_sum_(total)
+            world.all_reduce_(total)
             dt, _ = ops.bn_backward_apply(gy, t, y, gamma.detach(), mean, rstd, total, ctx.n_total, ctx.relu)
             return dt, local[1], local[0], None, None       # parameter gradients stay local: the gradient all-reduce sums them
         dt, dgamma, dbeta, _ = ops.bn_relu_backward(gy, t, y, gamma.detach(), mean, rstd, ctx.relu)
         return dt, dgamma, dbeta, None, None
+
+
+def sharded_bn_statistics(world, t, bn):
+    """(mean, rstd, rows) of the GLOBAL batch for this rank's rows t, and the running-statistics update: local (mean, M2)
+    written into an exchange row, ONE collective, one merge launch (lcrec_bn_stats / lcrec_bn_merge_stats)."""
+    n_local, F = t.shape
+    row = torch.empty(2 * F + 1, dtype=torch.float32, device=t.device)
+    row[:1].fill_(float(n_local))
+    ops.bn_stats(t, row_out=row)
+    rows = world.exchange_rows(row)
+    known = getattr(world, "batch_rows", None)
+    n_total = known[1] if known is not None and known[0] == n_local else int(rows[:, 0].sum().item())
+    with torch.no_grad():
+        mean, rstd = ops.bn_merge_stats(rows, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    return mean, rstd, n_total
 
 
 def _own_batchnorm(bn, x):

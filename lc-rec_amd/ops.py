@@ -586,17 +586,40 @@ def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, db
     return dt, dgamma, dbeta, dbias
 
 
-def bn_stats(t):
-    """(mean, m2) of this rank's rows: m2 = sum (t - mean)^2 (lcrec_bn_stats)."""
+def bn_stats(t, row_out=None):
+    """(mean, m2) of this rank's rows: m2 = sum (t - mean)^2 (lcrec_bn_stats).
+    row_out: a float32 [2F+1] exchange row (n_r, mean[F], m2[F]) to write them into (slot 0 is the caller's)."""
     lib = _lib.load()
     t = _dev(t, "t")
     n, F = t.shape
-    mean = torch.empty(F, dtype=torch.float32, device=t.device)
-    m2 = torch.empty(F, dtype=torch.float32, device=t.device)
+    if row_out is not None:
+        if not (row_out.is_cuda and row_out.dtype == torch.float32 and row_out.is_contiguous() and row_out.numel() == 2 * F + 1):
+            raise _lib.LcrecError("row_out must be a contiguous float32 [2F+1] device tensor")
+        mean, m2 = row_out[1:F + 1], row_out[F + 1:]
+    else:
+        mean = torch.empty(F, dtype=torch.float32, device=t.device)
+        m2 = torch.empty(F, dtype=torch.float32, device=t.device)
     with _on(t.device):
         rc = lib.lcrec_bn_stats(_ptr(t), n, F, _ptr(mean), _ptr(m2), _stream_ptr())
     _lib.check(rc, "lcrec_bn_stats")
     return mean, m2
+
+
+def bn_merge_stats(rows, eps, momentum=0.0, running_mean=None, running_var=None):
+    """(mean, rstd) of the union of the ranks' rows from rows [world, 2F+1] = (n_r, mean_r, m2_r); updates the running
+    statistics in place when given (lcrec_bn_merge_stats)."""
+    lib = _lib.load()
+    rows = _dev(rows, "rows")
+    world, width = rows.shape
+    F = (width - 1) // 2
+    mean = torch.empty(F, dtype=torch.float32, device=rows.device)
+    rstd = torch.empty(F, dtype=torch.float32, device=rows.device)
+    with _on(rows.device):
+        rc = lib.lcrec_bn_merge_stats(_ptr(rows), world, F, float(eps), float(momentum), _ptr(mean), _ptr(rstd),
+                                      _ptr(None if running_mean is None else _vec(running_mean, "running_mean", F)),
+                                      _ptr(None if running_var is None else _vec(running_var, "running_var", F)), _stream_ptr())
+    _lib.check(rc, "lcrec_bn_merge_stats")
+    return mean, rstd
 
 
 def bn_relu_apply(t, gamma, beta, mean, rstd, relu=True):
@@ -612,8 +635,9 @@ def bn_relu_apply(t, gamma, beta, mean, rstd, relu=True):
     return y
 
 
-def bn_backward_reduce(gy, t, y, mean, rstd, relu=True):
-    """float32 [2, F]: (sum g, sum g * xhat) over this rank's rows (lcrec_bn_backward_reduce)."""
+def bn_backward_reduce(gy, t, y, mean, rstd, relu=True, dbeta_out=None, dgamma_out=None):
+    """float32 [2, F]: (sum g, sum g * xhat) over this rank's rows (lcrec_bn_backward_reduce); dbeta_out / dgamma_out
+    receive a copy of the two rows (this rank's share of the BatchNorm parameter gradients)."""
     lib = _lib.load()
     gy, t = _dev(gy, "gy"), _dev(t, "t")
     n, F = t.shape
@@ -621,19 +645,21 @@ def bn_backward_reduce(gy, t, y, mean, rstd, relu=True):
     with _on(t.device):
         rc = lib.lcrec_bn_backward_reduce(_ptr(gy), _ptr(t), _ptr(None if y is None else _dev(y, "y")), n, F,
                                           _ptr(_vec(mean, "mean", F)), _ptr(_vec(rstd, "rstd", F)), int(bool(relu)),
-                                          _ptr(sums[0]), _ptr(sums[1]), _stream_ptr())
+                                          _ptr(sums[0]), _ptr(sums[1]),
+                                          _ptr(None if dbeta_out is None else _vec(dbeta_out, "dbeta_out", F)),
+                                          _ptr(None if dgamma_out is None else _vec(dgamma_out, "dgamma_out", F)), _stream_ptr())
     _lib.check(rc, "lcrec_bn_backward_reduce")
     return sums
 
 
-def bn_backward_apply(gy, t, y, gamma, mean, rstd, sums, n_total, relu=True):
+def bn_backward_apply(gy, t, y, gamma, mean, rstd, sums, n_total, relu=True, dbias_out=None):
     """(dt, dbias) from the all-reduced [2, F] sums (lcrec_bn_backward_apply)."""
     lib = _lib.load()
     gy, t = _dev(gy, "gy"), _dev(t, "t")
     n, F = t.shape
     sums = _dev(sums, "sums")
     dt = torch.empty_like(t)
-    dbias = torch.empty(F, dtype=torch.float32, device=t.device)
+    dbias = _vec(dbias_out, "dbias_out", F) if dbias_out is not None else torch.empty(F, dtype=torch.float32, device=t.device)
     with _on(t.device):
         rc = lib.lcrec_bn_backward_apply(_ptr(gy), _ptr(t), _ptr(None if y is None else _dev(y, "y")), n, F,
                                          _ptr(_vec(gamma, "gamma", F)), _ptr(_vec(mean, "mean", F)), _ptr(_vec(rstd, "rstd", F)),
@@ -658,8 +684,9 @@ def relu_bias_backward(gy, y, relu=True, dbias_out=None, inplace=False):
     return g, dbias
 
 
-def recon_loss_grad(out, x, loss_type="mse", want_grad=True):
-    """(loss float32 scalar tensor, grad | None) of rqvae.py:74-85's reconstruction term."""
+def recon_loss_grad(out, x, loss_type="mse", want_grad=True, global_rows=None):
+    """(loss float32 scalar tensor, grad | None) of rqvae.py:74-85's reconstruction term.  global_rows: rows of the global
+    batch when `out` is one rank's shard of it -- loss and gradient are then this rank's share of the global mean's."""
     lib = _lib.load()
     out, x = _dev(out, "out"), _dev(x, "x")
     if out.shape != x.shape:
@@ -670,7 +697,8 @@ def recon_loss_grad(out, x, loss_type="mse", want_grad=True):
     loss = torch.empty((), dtype=torch.float32, device=out.device)
     with _on(out.device):
         ws = _workspace(lib.lcrec_train_reduce_workspace(), out.device)
-        rc = lib.lcrec_recon_loss_grad(_ptr(out), _ptr(x), out.numel(), int(loss_type == "l1"), _ptr(g), _ptr(loss), _ptr(ws),
+        total = 0 if global_rows is None else int(global_rows) * (out.numel() // max(1, out.shape[0]))
+        rc = lib.lcrec_recon_loss_grad(_ptr(out), _ptr(x), out.numel(), total, int(loss_type == "l1"), _ptr(g), _ptr(loss), _ptr(ws),
                                        ws.numel(), _stream_ptr())
     _lib.check(rc, "lcrec_recon_loss_grad")
     return loss, g

@@ -185,11 +185,34 @@ class Trainer(object):
             if reason is None:
                 kind = "linear" if self.lr_scheduler_type.lower() == "linear" else "constant"
                 self.engine = TrainEngine(self.model, self.optimizer, kind, self.warmup_steps, self.max_steps,
-                                          use_ema=self.use_ema)
+                                          use_ema=self.use_ema, dist=self.dist)
                 self.logger.info("training step: one captured hipGraph per batch size (lcrec_amd.engine)")
             else:
                 self.logger.info("training step: autograd path (%s)", reason)
         return self.engine
+
+    def _reducer(self):
+        """The autograd path's bucketed gradient all-reduce (dist.GradReducer), built on first use."""
+        if getattr(self, "grad_reducer", None) is None:
+            from .dist import GradReducer
+            self.grad_reducer = GradReducer(self.dist, list(self.model.parameters()))
+        return self.grad_reducer
+
+    def _set_global_batch(self, loader, data):
+        """Tell the distributed context this rank's and the global batch's row counts (the loader knows both without a
+        collective).  False: a global batch with fewer rows than ranks, which leaves some rank empty -- skipped on every
+        rank (the only deviation from the single-process epoch; the reference itself cannot train BatchNorm on 1 row)."""
+        n_local = int(data.shape[0])
+        n_global = getattr(loader, "last_global_rows", None)
+        if n_global is None or self.dist.world_size == 1:
+            n_global = self.dist.sum_int(n_local)
+        if n_global < self.dist.world_size:
+            if not getattr(self, "_warned_small", False):
+                self._warned_small = True
+                self.logger.warning("global batch of %d rows on %d ranks: skipped", n_global, self.dist.world_size)
+            return False
+        self.dist.set_batch(n_local, n_global)
+        return True
 
     def _train_epoch(self, train_data, epoch_idx):
         self.model.train()
@@ -199,6 +222,8 @@ class Trainer(object):
                              disable=not self._is_main())
             engine.begin_epoch()
             for data in iter_data:
+                if self.dist is not None and not self._set_global_batch(train_data, data):
+                    continue
                 engine.step(data.to(self.device))
             return engine.end_epoch(self.scheduler)      # raises "Training loss is nan" / solver errors of the epoch
         total_loss = torch.zeros((), dtype=torch.float64, device=self.device)
@@ -207,16 +232,14 @@ class Trainer(object):
                          disable=not self._is_main())
         params = list(self.model.parameters())          # one walk of the module tree per epoch, not per step
         # no host synchronisation inside a step: the launch queue stays a step ahead of the GPU
-        reducer = getattr(self, "grad_reducer", None) if self.dist is not None else None
+        reducer = self._reducer() if self.dist is not None else None
         with ops.deferred_checks() as checks:
             for data in iter_data:
                 data = data.to(self.device)
                 if reducer is not None:
-                    n_local = data.shape[0]
-                    n_global = getattr(train_data, "last_global_rows", None)
-                    if n_global is None or self.dist.world_size == 1:
-                        n_global = self.dist.sum_int(n_local)
-                    self.dist.set_batch(n_local, n_global)
+                    if not self._set_global_batch(train_data, data):
+                        continue
+                    n_local, n_global = self.dist.batch_rows
                     reducer.begin()                   # zeroes the flat gradient buffer the .grad views live in
                 else:
                     self.optimizer.zero_grad()

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, tmp, ema, bn=False, rccl=False):
+def _run(rank, world, port, tmp, ema, bn=False, rccl=False, engine="auto"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if world > 1 or rccl:
@@ -35,7 +35,7 @@ def _run(rank, world, port, tmp, ema, bn=False, rccl=False):
     argv = ["--data_path", "unused", "--ckpt_dir", os.path.join(tmp, f"ck{world}"), "--device", "cuda:0", "--batch_size", "96",
             "--epochs", "2", "--layers", "64", "32", "--e_dim", "16", "--num_emb_list", "32", "32", "32",
             "--sk_epsilons", "0.0", "0.0", "0.003", "--no_kmeans_init"] + (["--bn", "True"] if bn else ["--no_bn"]) \
-        + (["--ema_decay", "0.95"] if ema else [])
+        + (["--ema_decay", "0.95"] if ema else []) + ["--train_engine", engine]
     args = cli.parse_args(argv)
     ctx = ldist.init_from_env(args, backend="nccl" if rccl else "gloo", force=rccl)
     assert ctx.enabled == (world > 1 or rccl)
@@ -53,25 +53,31 @@ def _run(rank, world, port, tmp, ema, bn=False, rccl=False):
         sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         np.savez(os.path.join(tmp, f"world{world}{'rccl' if rccl else ''}.npz"), losses=np.array(losses), rate=rate,
                  launched=np.int64(getattr(getattr(trainer, "grad_reducer", None), "launched", 0)),
+                 collectives=np.int64(getattr(trainer.engine, "collectives", 0)),
+                 replays=np.int64(getattr(trainer.engine, "graph_replays", 0)),
                  ckpt_dirs=np.array(sorted(os.listdir(os.path.join(tmp, f"ck{world}")))), **sd)
     ldist.shutdown(ctx)
 
 
-@pytest.mark.parametrize("ema,bn", [(False, False), (True, False), (False, True)])
-def test_two_ranks_reproduce_the_single_process_epoch(hip, tmp_path, ema, bn):
+@pytest.mark.parametrize("ema,bn,engine", [(False, False, "auto"), (True, False, "auto"), (False, True, "auto"), (False, True, "off"),
+                                           (True, False, "off")])
+def test_two_ranks_reproduce_the_single_process_epoch(hip, tmp_path, ema, bn, engine):
     """bn=True is the de-facto recipe (index/run.sh:9 passes `--bn False`, which type=bool parses as True): its batch
-    statistics must be those of the GLOBAL batch (SyncBatchNorm semantics, one all-reduce per layer and direction in
-    layers._BatchNormAct), including on the ragged last batch where the ranks hold 6 rows each of 12."""
+    statistics must be those of the GLOBAL batch (SyncBatchNorm semantics, one collective per layer and direction),
+    including on the ragged last batch where the ranks hold 6 rows each of 12.  engine "auto": the straight-line step of
+    engine.py with its exchanges (eager over gloo); "off": the autograd path (layers._BatchNormAct, dist.GradReducer).
+    Both against the single-process engine epoch."""
     tmp = str(tmp_path)
     mp.spawn(_run, args=(1, 0, tmp, ema, bn), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), tmp, ema, bn), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, _free_port(), tmp, ema, bn, False, engine), nprocs=2, join=True)
     one, two = np.load(os.path.join(tmp, "world1.npz")), np.load(os.path.join(tmp, "world2.npz"))
     assert len(two["ckpt_dirs"]) == 1            # one time-stamped checkpoint directory for the job, not one per rank
+    assert (int(two["collectives"]) > 0) == (engine == "auto") and (int(two["launched"]) > 0) == (engine == "off")
     np.testing.assert_allclose(two["losses"], one["losses"], rtol=2e-4)
     assert float(two["rate"]) == pytest.approx(float(one["rate"]), abs=2e-2)
     worst = 0.0
     for k in one.files:
-        if k in ("losses", "rate", "ckpt_dirs", "launched"):
+        if k in ("losses", "rate", "ckpt_dirs", "launched", "collectives", "replays"):
             continue
         a, b = one[k], two[k]
         assert a.shape == b.shape, k
@@ -144,15 +150,20 @@ def test_sharded_index_generation_writes_the_single_process_file(hip, tmp_path):
     assert len(g1["rows"]) == len(g2["rows"]) and (g2["rows"] < 0.7 * g1["rows"]).all() and (g2["rows"] > 0.3 * g1["rows"]).all()
 
 
-def test_one_rank_rccl_group_runs_the_data_parallel_step(hip, tmp_path):
+@pytest.mark.parametrize("engine", ["auto", "off"])
+def test_one_rank_rccl_group_runs_the_data_parallel_step(hip, tmp_path, engine):
     """RCCL cannot put two ranks on one GPU, but a ONE-rank "nccl" group is a real RCCL communicator: broadcast of the
-    initial weights, the bucketed asynchronous gradient all-reduce from backward hooks, the BatchNorm statistics exchange,
-    the Sinkhorn-level gather, the loss all-reduce and the evaluation gather all run through it -- and must leave the
+    initial weights, the gradient all-reduce (engine: two asynchronous spans of its flat buffer CAPTURED in the step's
+    hipGraph with every other exchange; autograd path: buckets from backward hooks), the BatchNorm statistics exchange, the
+    Sinkhorn-level gather, the loss all-reduce and the evaluation gather all run through it -- and must leave the
     single-process epoch (the engine's) unchanged."""
     tmp = str(tmp_path)
     mp.spawn(_run, args=(1, 0, tmp, False, True), nprocs=1, join=True)
-    mp.spawn(_run, args=(1, _free_port(), tmp, False, True, True), nprocs=1, join=True)
+    mp.spawn(_run, args=(1, _free_port(), tmp, False, True, True, engine), nprocs=1, join=True)
     one, two = np.load(os.path.join(tmp, "world1.npz")), np.load(os.path.join(tmp, "world1rccl.npz"))
-    assert int(two["launched"]) > 0                    # buckets left from backward hooks, over RCCL
+    if engine == "auto":
+        assert int(two["collectives"]) > 0 and int(two["replays"]) > 0      # the exchanges were captured and replayed
+    else:
+        assert int(two["launched"]) > 0                # buckets left from backward hooks, over RCCL
     np.testing.assert_allclose(two["losses"], one["losses"], rtol=2e-4)
     assert float(two["rate"]) == pytest.approx(float(one["rate"]), abs=2e-2)

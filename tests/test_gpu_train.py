@@ -57,6 +57,69 @@ def test_bn_relu_forward_backward_match_torch(hip, n, feat, relu):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("cuts,feat,relu", [((0, 60, 120, 175), 96, True), ((0, 1, 9, 1024), 2048, True), ((0, 500, 500, 777), 100, False)])
+def test_sharded_batchnorm_kernels_give_the_whole_batch_result(hip, cuts, feat, relu):
+    """The data-parallel split of the BatchNorm step (lcrec_bn_stats -> exchange -> lcrec_bn_merge_stats -> lcrec_bn_relu_apply;
+    lcrec_bn_backward_reduce -> all-reduce -> lcrec_bn_backward_apply) on three shards of a batch (one of them possibly
+    one row, or empty-adjacent): the union must be nn.BatchNorm1d's result on the whole batch (torch fp64 on the CPU),
+    the parameter-gradient shares must sum to the whole-batch gradients, and the sharded loss/gradient of the
+    reconstruction term must sum to the global mean's."""
+    n = cuts[-1]
+    rs = _rs(n + feat)
+    t = gi.f32(rs.standard_normal((n, feat)) * 2.0 + rs.standard_normal(feat) * 3.0)
+    gamma, beta = gi.f32(1 + 0.2 * rs.standard_normal(feat)), gi.f32(0.3 * rs.standard_normal(feat))
+    rm, rv = gi.f32(0.1 * rs.standard_normal(feat)), gi.f32(0.5 + rs.uniform(size=feat))
+    gy = gi.f32(rs.standard_normal((n, feat)))
+    td = torch.from_numpy(t).double().requires_grad_(True)
+    gd, bd = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    rmd, rvd = torch.from_numpy(rm).double(), torch.from_numpy(rv).double()
+    yd = F.batch_norm(td, rmd, rvd, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    if relu:
+        yd = F.relu(yd)
+    yd.backward(torch.from_numpy(gy).double())
+    dev = torch.device(DEV)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    shards = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    rows = torch.zeros((len(shards), 2 * feat + 1), dtype=torch.float32, device=dev)
+    for r, (a, b) in enumerate(shards):
+        rows[r, 0] = b - a
+        hip.ops.bn_stats(d(t[a:b]), row_out=rows[r])
+    rm_d, rv_d = d(rm), d(rv)
+    mean, rstd = hip.ops.bn_merge_stats(rows, 1e-5, 0.1, rm_d, rv_d)
+    np.testing.assert_allclose(mean.cpu().numpy(), t.astype(np.float64).mean(0), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), 1 / np.sqrt(t.astype(np.float64).var(0) + 1e-5), rtol=1e-5)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rmd.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rvd.numpy(), rtol=1e-5, atol=1e-6)
+    ys = [hip.ops.bn_relu_apply(d(t[a:b]), d(gamma), d(beta), mean, rstd, relu) for a, b in shards]
+    np.testing.assert_allclose(torch.cat(ys).cpu().numpy(), yd.detach().numpy(), rtol=1e-5, atol=1e-5)
+    dbeta = [torch.zeros(feat, device=dev) for _ in shards]
+    dgamma = [torch.zeros(feat, device=dev) for _ in shards]
+    local = [hip.ops.bn_backward_reduce(d(gy[a:b]), d(t[a:b]), y, mean, rstd, relu, dbeta_out=dbeta[r], dgamma_out=dgamma[r])
+             for r, ((a, b), y) in enumerate(zip(shards, ys))]
+    for r in range(len(shards)):
+        assert torch.equal(local[r][0], dbeta[r]) and torch.equal(local[r][1], dgamma[r])
+    total = torch.stack(local).sum(0)
+    np.testing.assert_allclose(total[1].cpu().numpy(), gd.grad.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(total[0].cpu().numpy(), bd.grad.numpy(), rtol=1e-5, atol=1e-4)
+    dts = []
+    for (a, b), y in zip(shards, ys):
+        bias_grad = torch.full((feat,), 7.0, device=dev)
+        dt, db = hip.ops.bn_backward_apply(d(gy[a:b]), d(t[a:b]), y, d(gamma), mean, rstd, total, n, relu, dbias_out=bias_grad)
+        assert db.data_ptr() == bias_grad.data_ptr()
+        np.testing.assert_allclose(db.cpu().numpy(), dt.double().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4)
+        dts.append(dt)
+    scale = float(np.abs(td.grad.numpy()).max())
+    np.testing.assert_allclose(torch.cat(dts).cpu().numpy(), td.grad.numpy(), rtol=1e-4, atol=2e-6 * max(scale, 1.0))
+    # reconstruction term: shares of the global mean and of its gradient
+    for kind, fn in (("mse", F.mse_loss), ("l1", F.l1_loss)):
+        out = torch.from_numpy(gy).requires_grad_(True)
+        ref = fn(out, torch.from_numpy(t), reduction="mean")
+        ref.backward()
+        parts = [hip.ops.recon_loss_grad(d(gy[a:b]), d(t[a:b]), kind, global_rows=n) for a, b in shards]
+        np.testing.assert_allclose(sum(float(p[0]) for p in parts), ref.item(), rtol=1e-6)
+        np.testing.assert_allclose(torch.cat([p[1] for p in parts]).cpu().numpy(), out.grad.numpy(), rtol=1e-6, atol=1e-12)
+
+
 def test_relu_bias_backward_and_losses_match_torch(hip):
     rs = _rs(11)
     dev = torch.device(DEV)

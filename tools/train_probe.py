@@ -30,11 +30,20 @@ def trainer_probe(a):
                 "--sk_epsilons", "0.0", "0.0", "0.0", "0.0" if a.no_sk else "0.003"] \
             + (["--bn", "True"] if a.bn else ["--no_bn"]) + (["--strict_nan_check"] if a.strict else []) + ["--train_engine", a.engine]
         args = cli.parse_args(argv)
+        ctx = None
+        if a.rccl1:
+            # a ONE-rank RCCL group: the data-parallel step with every exchange going through the backend (what an 8-GPU
+            # rank launches, minus the wire time)
+            from lcrec_amd import dist as ldist
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+            ctx = ldist.init_from_env(args, backend="nccl", force=True)
         cli.seed_everything(2024)
         model = cli.build_model(args, a.in_dim)
         data = torch.randn((n, a.in_dim), device=dev)
         loader = DeviceLoader(data, a.batch, True, dev)
         trainer = Trainer(args, model, len(loader))
+        if ctx is not None:
+            ldist.attach(trainer, ctx)
         trainer._train_epoch(loader, 0)
         torch.cuda.synchronize()
         prof = None
@@ -54,7 +63,10 @@ def trainer_probe(a):
             pstats.Stats(prof).sort_stats("tottime").print_stats(30)
         steps = epochs * len(loader)
         eng = trainer.engine
-        print(f"Trainer._train_epoch: in_dim {a.in_dim} batch {a.batch} levels 4 sinkhorn {not a.no_sk} bn {a.bn} strict_nan_check {a.strict} "
+        if ctx is not None:
+            ldist.shutdown(ctx)
+        print(f"Trainer._train_epoch{' [one-rank RCCL group, %d collectives/step]' % (eng.collectives // 2 if eng is not None else -1) if a.rccl1 else ''}: "
+              f"in_dim {a.in_dim} batch {a.batch} levels 4 sinkhorn {not a.no_sk} bn {a.bn} strict_nan_check {a.strict} "
               f"engine {'hipGraph (%d replays)' % eng.graph_replays if eng is not None else 'off (autograd path)'}: "
               f"{dt / steps * 1e3:.3f} ms/step, {a.batch * steps / dt:,.0f} items/s")
 
@@ -70,6 +82,7 @@ def main():
     ap.add_argument("--strict", action="store_true", help="with --trainer: the per-step NaN host sync of the reference")
     ap.add_argument("--cprofile", action="store_true", help="with --trainer: cProfile of the timed epochs")
     ap.add_argument("--engine", default="auto", choices=["auto", "off"], help="with --trainer: --train_engine of lcrec_amd.main")
+    ap.add_argument("--rccl1", action="store_true", help="with --trainer: data-parallel step on a one-rank RCCL group")
     ap.add_argument("--trainer", action="store_true",
                     help="time lcrec_amd.trainer.Trainer._train_epoch itself (loader, NaN check, fused AdamW, schedule)")
     a = ap.parse_args()
