@@ -97,8 +97,19 @@ def _worker(rank, world, port, tmp):
     torch.manual_seed(5)
     full = list(DeviceLoader(data, batch_size=8, shuffle=True, device="cpu"))
     for part, whole in zip(mine, full):
-        per = (whole.shape[0] + world - 1) // world
-        assert torch.equal(part, whole[rank * per:(rank + 1) * per])
+        a, b = ldist.batch_slice(whole.shape[0], rank, world)
+        assert torch.equal(part, whole[a:b])
+    # as even as contiguous slices allow (Games' last batch: 475 rows on 8 ranks), never an empty rank unless m < world
+    assert ldist.batch_counts(475, 8) == [60, 60, 60, 59, 59, 59, 59, 59] and ldist.batch_counts(3, 4) == [1, 1, 1, 0]
+    assert ldist.batch_slice(475, 3, 8) == (180, 239) and ldist.batch_slice(9, 1, 2) == (5, 9)
+    # the engine's exchanges: row counts from the loader's split (no collective), one-collective exchange of a small row
+    ctx.set_batch(5 if rank == 0 else 4, 9)
+    assert ctx.row_counts(5 if rank == 0 else 4) == [5, 4] and ctx.row_counts(3) is None
+    got = ctx.exchange_rows(torch.tensor([float(rank), 2.0 * rank + 1.0, 7.0]))
+    assert torch.equal(got, torch.tensor([[0.0, 1.0, 7.0], [1.0, 3.0, 7.0]]))
+    red = torch.tensor([1.0 + rank, 10.0])
+    ctx.all_reduce_(red)
+    assert torch.equal(red, torch.tensor([3.0, 20.0]))
     assert ldist.shard_range(10, rank, world) == ((0, 5) if rank == 0 else (5, 10))
     assert ldist.shard_range(7, 1, 4) == (2, 4) and ldist.shard_range(3, 3, 4) == (3, 3)
 
