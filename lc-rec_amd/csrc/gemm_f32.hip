@@ -64,17 +64,40 @@ __device__ unsigned long long g_gen_stamps[4][64][6];
             g_gen_stamps[wave][kt - kt0][slot] = t_;                                               \
         }                                                                                          \
     } while (0)
+// whole-kernel marks of the same workgroup (entry, K loop start, K loop end, epilogue end) in the unused K-tile row 60
+#define LCREC_GMARK(slot)                                                                          \
+    do {                                                                                           \
+        if (bid == 9 && split == 0 && lane == 0) {                                                 \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            g_gen_stamps[wave][60][slot] = t_;                                                     \
+        }                                                                                          \
+    } while (0)
 #else
 #define LCREC_STAMP(slot) do { } while (0)
 #define LCREC_MARK(slot) do { } while (0)
 #define LCREC_GSTAMP(slot) do { } while (0)
+#define LCREC_GMARK(slot) do { } while (0)
 #endif
 
 template <int N>
 struct IntC { static constexpr int value = N; };
 
+// f(IntC<0>{}) ... f(IntC<N-1>{}): a loop whose index is a compile-time constant in the body
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 constexpr int BK = 32;   // K slice per step
 constexpr int LDK = 36;  // padded LDS row length in floats
+#ifndef LCREC_GEMM_RING
+#define LCREC_GEMM_RING 4   // register sets of the 64 x 64 kernel's global prefetch ring (see linear_tile_body)
+#endif
 
 template <int ROWS>
 struct StageRegs {
@@ -255,6 +278,7 @@ __device__ __forceinline__ void linear_tile_body(
     // and one barrier per K-tile moved the time by more than 3 % either way, and 128 x 64 / 64 x 128 tiles were slower
     // on all but the widest layer: those launches are 15-90 us and bound by their few K-chains per SIMD.)
 
+    LCREC_GMARK(0);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -325,6 +349,10 @@ __device__ __forceinline__ void linear_tile_body(
     };
     const int t_g = ((tid >> 2) * K + (tid & 3) * 8) * 4;
     const uint32_t t_s = (uint32_t)(((tid >> 2) * LDK + (tid & 3) * 8) * 4);
+    // the ring's form of the same (load_piece / store_piece): byte offset of the thread's 16 bytes in a row's first 64, and
+    // where its first value goes in the row's LDS image
+    const int t_q = ((tid >> 2) * K) * 4 + (tid & 3) * 16;
+    const uint32_t t_w = (uint32_t)(((tid >> 2) * LDK + ((tid & 3) >> 1) * 8 + ((tid & 3) & 1) * 2) * 4);
     auto fast_load = [&](auto &r, __amdgpu_buffer_rsrc_t rs, int rows, int kt, bool live) {
         constexpr int IT = sizeof(r.v) / sizeof(r.v[0]);
 #pragma unroll
@@ -417,37 +445,149 @@ __device__ __forceinline__ void linear_tile_body(
         }
         LCREC_GSTAMP(5);
     };
-    // DB form of the same K-tile: reads buffer `cur`, stores K-tile kt+1 into the other one between the MFMA groups.  The
-    // stores are unconditional (past the end the registers hold the zeros of an out-of-range load and nobody reads the
-    // buffer), so there is no branch for the compiler's waitcnt bookkeeping to merge over.
-    auto k_tile_db = [&](int kt, StageRegs<BM> &ra_free, StageRegs<BN> &rw_free, const StageRegs<BM> &ra_next, const StageRegs<BN> &rw_next,
-                         auto cur_c) {
-        constexpr int cur = decltype(cur_c)::value;
-        stage_in(kt + 2, ra_free, rw_free, kt + 2 < nk);
-        f32x4 af[4], wf[4];
+    // DB form (the 64 x 64 tile): the operand fragments of K-tile kt+1 are read from LDS into a SECOND register set while
+    // K-tile kt's 16 MFMAs run from the first, and K-tile kt+2 (global loads issued two iterations ago) is stored into the
+    // buffer K-tile kt was read from -- one LDS instruction after each MFMA, so the in-order wave never queues more LDS
+    // work than fits in an MFMA's 64 cycles.  One barrier per K-tile; nothing but the barrier itself is exposed:
+    //   iteration kt:   global loads kt+RING+1 -> free set | MFMA(kt) from F[kt&1] | LDS reads kt+1 -> F[~kt&1] from buf[~kt&1]
+    //                   | LDS stores kt+2 -> buf[kt&1] | wait, barrier
+    // (first form: fragments read at the top of the iteration -- an exposed LDS round trip per K-tile with one workgroup
+    // per CU -- and the stores in one block after the fourth MFMA, where the in-order wave stalled on the LDS queue: 1 770
+    // cycles per K-tile against the MFMA pipe's 1 024.)  Stores and loads are unconditional (a K-tile past the end is
+    // zeros from an out-of-range load; nobody multiplies it), so there is no branch for the waitcnt bookkeeping to merge.
+    struct Frag { f32x4 a[4], w[4]; };
+    auto frag_read = [&](Frag &f, auto slot_c, int buf) {
+        constexpr int slot = decltype(slot_c)::value, g = slot & 3;
+        if constexpr (slot < 4) f.a[g] = *reinterpret_cast<const f32x4 *>(a_base + buf * BUF + g * 8);
+        else f.w[g] = *reinterpret_cast<const f32x4 *>(w_base + buf * BUF + g * 8);
+    };
+    // quarter `piece` of a K-tile's LDS stores: operand A (0, 1) or W (2, 3), first or second half of the thread's share
+    auto store_piece = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_, int buf, auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value, half = piece & 1;
+        auto one = [&](const auto &r, float *lds, auto rows_c, auto kmajor_c) {
+            constexpr int ROWS = decltype(rows_c)::value;
+            if constexpr (decltype(kmajor_c)::value) {
+                constexpr int Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;      // (Q * 32 >= 256: every thread has a share)
+                const int kk = tid / Q, r4 = tid % Q;
+                const int slot = (kk & ~7) + ((kk & 1) << 2) + ((kk >> 1) & 3);
+                const uint32_t addr = lds_addr(lds) + (uint32_t)((r4 * 4 * LDK + slot) * 4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            af[g] = *reinterpret_cast<const f32x4 *>(a_base + cur * BUF + g * 8);
-            wf[g] = *reinterpret_cast<const f32x4 *>(w_base + cur * BUF + g * 8);
-        }
+                for (int j = half; j < NL; j += 2) {
+                    const f32x4 v = r.v[j >> 1][j & 1];
+                    const uint32_t a = addr + j * KSTEP * 4;
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset1:36" ::"v"(a), "v"(v[0]), "v"(v[1]) : "memory");
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:72 offset1:108" ::"v"(a), "v"(v[2]), "v"(v[3]) : "memory");
+                }
+            } else {
+                constexpr int IT = sizeof(r.v) / sizeof(r.v[0]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][q], wf[g][q], acc[0][0], 0, 0, 0);
-            if (g == 0) {                                   // the first four MFMAs are queued: now the stores
-                __builtin_amdgcn_sched_barrier(0);
-                stage_out_into(ra_next, rw_next, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int it = 0; it < IT; ++it)
+                    if (ROWS % 64 == 0 || (tid >> 2) + it * 64 < ROWS) {          // (a 64-row multiple: every thread has a share)
+                        // k = 16*half + 4c + i (c = tid & 3) -> group of eight 2*half + c/2, slot (k&1)*4 + (k%8)/2: i = 0, 2 are
+                        // neighbours, i = 1, 3 four slots further.  Banks: 4*row + 8*(c/2) + 2*(c&1) (+1) -- the 32 lanes of a
+                        // store half spread two-deep over 16 banks, which a ds_write2_b32's transfer time covers: no conflicts,
+                        // no v_mov (the first form's four ds_write2_b32 per eight floats landed on 8 banks each: 4x)
+                        const uint32_t a = lds_addr(lds) + t_w + (uint32_t)((it * 64 * LDK + half * 16) * 4);
+                        const f32x4 v = r.v[it][half];
+                        asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(a), "v"(v[0]), "v"(v[2]) : "memory");
+                        asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" ::"v"(a), "v"(v[1]), "v"(v[3]) : "memory");
+                    }
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads of `cur` and stores into the other buffer
-        __syncthreads();
+        };
+        if constexpr (piece < 2) one(ra_, As + buf * BUF, IntC<BM>{}, IntC<TA ? 1 : 0>{});
+        else one(rw_, Ws + buf * BUF, IntC<BN>{}, IntC<TB ? 1 : 0>{});
+    };
+    // quarter `piece` of a K-tile's global loads, split like the stores: operand A (0, 1) or W (2, 3), first or second 16 bytes
+    // of each of the thread's 32-byte shares.  Issued one per MFMA gap: at the top of the iteration the four waves' sixteen
+    // 1-KB loads reached the texture-address unit (64 B per clock) together and every wave sat in its issue for 150-300 cycles.
+    auto load_piece = [&](StageRegs<BM> &ra_, StageRegs<BN> &rw_, int kt, bool live, auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value, half = piece & 1;
+        auto one = [&](auto &r, __amdgpu_buffer_rsrc_t rs, auto rows_c, auto kmajor_c, int64_t R, int64_t r0) {
+            constexpr int ROWS = decltype(rows_c)::value;
+            if constexpr (decltype(kmajor_c)::value) {
+                constexpr int Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;
+                const int kk = tid / Q, r4 = tid % Q;
+                const bool ok = tid < Q * 32 && r0 + r4 * 4 < R;
+                const int vo = ok ? (int)((kk * R + r4 * 4) * 4) : 0x7fffff00;
+#pragma unroll
+                for (int j = half; j < NL; j += 2) {
+                    const unsigned so = live ? (unsigned)(((int64_t)kt * BK + j * KSTEP) * R * 4) : SOFF_OUT;
+                    r.v[j >> 1][j & 1] = buffer_load_f32x4(rs, vo, (int)so);
+                }
+            } else {
+                constexpr int IT = sizeof(r.v) / sizeof(r.v[0]);
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    // the four lanes of a row take 64 CONTIGUOUS bytes per instruction (k = 16*half + 4*(tid&3) ..+3), not four
+                    // 16-byte pieces 32 bytes apart as the prologue's two-loads-per-thread form does
+                    const bool in_tile = (tid >> 2) + it * 64 < ROWS;
+                    const int vo = in_tile ? t_q : 0x7fffff00;
+                    const unsigned so = live ? (unsigned)(kt * (BK * 4) + it * 64 * K * 4) : SOFF_OUT;
+                    r.v[it][half] = buffer_load_f32x4(rs, vo + half * 64, (int)so);
+                }
+            }
+        };
+        if constexpr (piece < 2) one(ra_, a_rsrc, IntC<BM>{}, IntC<TA ? 1 : 0>{}, M, m0);
+        else one(rw_, w_rsrc, IntC<BN>{}, IntC<TB ? 1 : 0>{}, N, n0);
+    };
+    auto k_tile_rb = [&](int kt, StageRegs<BM> &ra_free, StageRegs<BN> &rw_free, const StageRegs<BM> &ra_next, const StageRegs<BN> &rw_next,
+                         const Frag &fc, Frag &fn, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        LCREC_GSTAMP(0);
+        const bool live = kt + LCREC_GEMM_RING + 1 < nk;
+        LCREC_GSTAMP(1);
+        static_for<16>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value, g = s >> 2, q = s & 3;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc.a[g][q], fc.w[g][q], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef LCREC_RB_EXP
+#define LCREC_RB_EXP 0
+#endif
+            if constexpr (s < 8) { if constexpr (LCREC_RB_EXP != 2) frag_read(fn, IntC<s>{}, cur ^ 1); }
+            if constexpr (s < 8 && (s & 1) == 0 && LCREC_RB_EXP != 4) load_piece(ra_free, rw_free, kt + LCREC_GEMM_RING + 1, live, IntC<s / 2>{});
+            else if constexpr ((s & 1) == 0 && LCREC_RB_EXP != 1) store_piece(ra_next, rw_next, cur, IntC<(s - 8) / 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s == 7) LCREC_GSTAMP(2);
+        });
+        LCREC_GSTAMP(3);
+        if constexpr (LCREC_RB_EXP != 5)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads and its stores
+        LCREC_GSTAMP(4);
+        if constexpr (LCREC_RB_EXP != 3) __syncthreads();
+        LCREC_GSTAMP(5);
     };
     if constexpr (DB) {
-        for (int kt = kt0; kt < nk; kt += 2) {
-            k_tile_db(kt, ra, rw, ra2, rw2, IntC<0>{});
-            if (kt + 1 < nk) k_tile_db(kt + 1, ra2, rw2, ra, rw, IntC<1>{});
+        // Global prefetch: a ring of RING register sets; K-tile kt0+j lives in set j % RING, is loaded RING-1 iterations
+        // before it is stored to LDS, i.e. RING-1 K-tiles (16 KB each) are in flight per workgroup.  With one workgroup per
+        // CU and every operand line a first touch at the chip's frontier (all workgroups walk K in step), the loaded
+        // latency is 1-2 us: two K-tiles in flight (the first form) cover ~0.9 us of MFMA work at best.
+        constexpr int RING = LCREC_GEMM_RING;
+        static_assert(RING >= 2 && RING % 2 == 0, "the fragment sets alternate with the parity of the ring slot");
+        Frag fa, fb;
+        StageRegs<BM> sa[RING];
+        StageRegs<BN> sw[RING];
+        if (kt0 < nk) {
+            // the prologue above left K-tile kt0 in buffer 0 and K-tile kt0+1 in (ra2, rw2)
+            stage_out_into(ra2, rw2, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the ring's sets hold a K-tile in load_piece's register convention, which store_piece expects)
+            static_for<RING - 2>([&](auto j_c) {                             // K-tiles 2 .. RING-1 into their own sets
+                constexpr int j = decltype(j_c)::value + 2;
+                static_for<4>([&](auto p_c) { load_piece(sa[j], sw[j], kt0 + j, kt0 + j < nk, p_c); });
+            });
+            static_for<4>([&](auto p_c) { load_piece(sa[0], sw[0], kt0 + RING, kt0 + RING < nk, p_c); });   // set 0's K-tile is in LDS already
+            __syncthreads();
+            static_for<8>([&](auto s_c) { frag_read(fa, s_c, 0); });
+        }
+        LCREC_GMARK(1);
+        for (int kt = kt0; kt < nk; kt += RING) {
+            static_for<RING>([&](auto u_c) {
+                constexpr int u = decltype(u_c)::value;
+                if (u == 0 || kt + u < nk) {
+                    if constexpr (u % 2 == 0) k_tile_rb(kt + u, sa[(u + 1) % RING], sw[(u + 1) % RING], sa[(u + 2) % RING], sw[(u + 2) % RING], fa, fb, IntC<0>{});
+                    else k_tile_rb(kt + u, sa[(u + 1) % RING], sw[(u + 1) % RING], sa[(u + 2) % RING], sw[(u + 2) % RING], fb, fa, IntC<1>{});
+                }
+            });
         }
     } else {
         for (int kt = kt0; kt < nk; kt += 2) {              // unrolled by two so that both register sets are static
@@ -456,6 +596,7 @@ __device__ __forceinline__ void linear_tile_body(
         }
     }
 
+    LCREC_GMARK(2);
     // epilogue (every wave passed the loop's last barrier after its final LDS operand read, so the
     // activation tile's LDS can be reused: 32 rows per wave)
     float *stg = As + wave * 32 * LDK;
@@ -465,6 +606,7 @@ __device__ __forceinline__ void linear_tile_body(
         for (int i = 0; i < TM; ++i)
             store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * TM * 32 + i * 32, M, n0 + wn * TN * 32 + j * 32, N, bias,
                              bn_scale, bn_shift, relu);
+    LCREC_GMARK(3);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, bool TB = false>
