@@ -381,13 +381,6 @@ __device__ __forceinline__ void linear_tile_body(
             stage_load<BN>(rw_, W, n0, N, K, kt * BK, tid);
         }
     };
-    // (DB only) the stores alone, into buffer `buf`; the caller waits for them (lgkmcnt) before its barrier
-    auto stage_out_into = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_, int buf) {
-        if constexpr (TA) kmajor_store(ra_, As + buf * BUF, IntC<BM>{});
-        else fast_store(ra_, As + buf * BUF, BM);
-        if constexpr (TB) kmajor_store(rw_, Ws + buf * BUF, IntC<BN>{});
-        else fast_store(rw_, Ws + buf * BUF, BN);
-    };
     auto stage_out = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_) {
         if constexpr (FAST) {
             if constexpr (TA) kmajor_store(ra_, As, IntC<BM>{});
@@ -401,12 +394,14 @@ __device__ __forceinline__ void linear_tile_body(
         }
     };
 
-    if (kt0 < nk) {
-        stage_in(kt0, ra, rw, true);
-        stage_out(ra, rw);
-        stage_in(kt0 + 1, ra2, rw2, kt0 + 1 < nk);        // K-tile kt0+1 waits in the second set
+    if constexpr (!DB) {
+        if (kt0 < nk) {
+            stage_in(kt0, ra, rw, true);
+            stage_out(ra, rw);
+            stage_in(kt0 + 1, ra2, rw2, kt0 + 1 < nk);    // K-tile kt0+1 waits in the second set
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const float *a_base = As + (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     const float *w_base = Ws + (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
@@ -456,10 +451,31 @@ __device__ __forceinline__ void linear_tile_body(
     // cycles per K-tile against the MFMA pipe's 1 024.)  Stores and loads are unconditional (a K-tile past the end is
     // zeros from an out-of-range load; nobody multiplies it), so there is no branch for the waitcnt bookkeeping to merge.
     struct Frag { f32x4 a[4], w[4]; };
+    // A K-MAJOR operand (TA / TB: the backward products) keeps its LDS image k-major too in this form: [32 k][ROWS], no
+    // padding.  Its global loads are 16 bytes = four rows of one k, so a K-tile goes to LDS with one conflict-free
+    // ds_write_b128 per load (row-major image: four rows 36 floats apart per load, 16 r4 + 4 i + slot mod 32 -- the 32 lanes
+    // of a store half on FOUR banks, 8 cycles per dword where one would do: ~1 000 LDS cycles per K-tile when both operands
+    // are k-major, as in dW); a fragment is then four 4-byte reads at (k = 8g + 2q + lane/32, row): consecutive lanes,
+    // consecutive dwords, and the compiler pairs them into ds_read2st64_b32.  No de-interleaving: k is the address.
+    const float *ak_base = As + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
+    const float *wk_base = Ws + (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
     auto frag_read = [&](Frag &f, auto slot_c, int buf) {
         constexpr int slot = decltype(slot_c)::value, g = slot & 3;
-        if constexpr (slot < 4) f.a[g] = *reinterpret_cast<const f32x4 *>(a_base + buf * BUF + g * 8);
-        else f.w[g] = *reinterpret_cast<const f32x4 *>(w_base + buf * BUF + g * 8);
+        if constexpr (slot < 4) {
+            if constexpr (TA) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.a[g][q] = ak_base[buf * BUF + (8 * g + 2 * q) * BM];
+            } else {
+                f.a[g] = *reinterpret_cast<const f32x4 *>(a_base + buf * BUF + g * 8);
+            }
+        } else {
+            if constexpr (TB) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.w[g][q] = wk_base[buf * BUF + (8 * g + 2 * q) * BN];
+            } else {
+                f.w[g] = *reinterpret_cast<const f32x4 *>(w_base + buf * BUF + g * 8);
+            }
+        }
     };
     // quarter `piece` of a K-tile's LDS stores: operand A (0, 1) or W (2, 3), first or second half of the thread's share
     auto store_piece = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_, int buf, auto piece_c) {
@@ -469,14 +485,11 @@ __device__ __forceinline__ void linear_tile_body(
             if constexpr (decltype(kmajor_c)::value) {
                 constexpr int Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;      // (Q * 32 >= 256: every thread has a share)
                 const int kk = tid / Q, r4 = tid % Q;
-                const int slot = (kk & ~7) + ((kk & 1) << 2) + ((kk >> 1) & 3);
-                const uint32_t addr = lds_addr(lds) + (uint32_t)((r4 * 4 * LDK + slot) * 4);
+                const uint32_t addr = lds_addr(lds) + (uint32_t)((kk * ROWS + r4 * 4) * 4);
 #pragma unroll
                 for (int j = half; j < NL; j += 2) {
                     const f32x4 v = r.v[j >> 1][j & 1];
-                    const uint32_t a = addr + j * KSTEP * 4;
-                    asm volatile("ds_write2_b32 %0, %1, %2 offset1:36" ::"v"(a), "v"(v[0]), "v"(v[1]) : "memory");
-                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:72 offset1:108" ::"v"(a), "v"(v[2]), "v"(v[3]) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(addr + (uint32_t)(j * KSTEP * ROWS * 4)), "v"(v) : "memory");
                 }
             } else {
                 constexpr int IT = sizeof(r.v) / sizeof(r.v[0]);
@@ -567,15 +580,18 @@ __device__ __forceinline__ void linear_tile_body(
         StageRegs<BM> sa[RING];
         StageRegs<BN> sw[RING];
         if (kt0 < nk) {
-            // the prologue above left K-tile kt0 in buffer 0 and K-tile kt0+1 in (ra2, rw2)
-            stage_out_into(ra2, rw2, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // (the ring's sets hold a K-tile in load_piece's register convention, which store_piece expects)
-            static_for<RING - 2>([&](auto j_c) {                             // K-tiles 2 .. RING-1 into their own sets
+            // K-tiles 0 and 1 through sets 0 and 1 into the two buffers, then the ring is filled: K-tiles 2 .. RING-1 into their
+            // own sets, K-tile RING into set 0 (whose K-tile is in LDS by then); iteration 0 loads K-tile RING+1 into set 1
+            static_for<4>([&](auto p_c) { load_piece(sa[0], sw[0], kt0, true, p_c); });
+            static_for<4>([&](auto p_c) { load_piece(sa[1], sw[1], kt0 + 1, kt0 + 1 < nk, p_c); });
+            static_for<RING - 2>([&](auto j_c) {
                 constexpr int j = decltype(j_c)::value + 2;
                 static_for<4>([&](auto p_c) { load_piece(sa[j], sw[j], kt0 + j, kt0 + j < nk, p_c); });
             });
-            static_for<4>([&](auto p_c) { load_piece(sa[0], sw[0], kt0 + RING, kt0 + RING < nk, p_c); });   // set 0's K-tile is in LDS already
+            static_for<4>([&](auto p_c) { store_piece(sa[0], sw[0], 0, p_c); });
+            static_for<4>([&](auto p_c) { store_piece(sa[1], sw[1], 1, p_c); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_for<4>([&](auto p_c) { load_piece(sa[0], sw[0], kt0 + RING, kt0 + RING < nk, p_c); });
             __syncthreads();
             static_for<8>([&](auto s_c) { frag_read(fa, s_c, 0); });
         }
