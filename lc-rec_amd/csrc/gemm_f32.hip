@@ -242,11 +242,12 @@ __device__ __forceinline__ void linear_tile_body(
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     // one allocation: the epilogue stages 4 x 32 output rows from its start, which is more than As when BM = 64
     static_assert(BM + BN >= 128, "the epilogue needs 128 staging rows");
-    // DB (the 64 x 64 tile of batch-sized launches): two LDS buffers, ONE barrier per K-tile, and K-tile kt+1's LDS stores
-    // issued between K-tile kt's MFMAs.  In-kernel stamps (tools/generic_stamp_probe.py) had the stores at 670 of a K-tile's
-    // 2 500 cycles: every ds_write2_b32 of the de-interleaving store hits 8 of the 32 banks (all bases are multiples of 4
-    // dwords, both halves of a pair land on the same residue), and with one workgroup per CU nothing ran under them.  In
-    // the second buffer they run under the 1 024 cycles the MFMA pipe needs anyway.
+    // DB (the one-accumulator tiles, 64 x 64 and 128 x 32, of batch-sized launches -- about one workgroup per CU, one wave per
+    // SIMD, nothing else to run under a stall): two LDS buffers, two fragment register sets, ONE barrier per K-tile, and every
+    // load, LDS store and fragment read of the NEXT K-tiles issued one per gap between the current K-tile's 16 MFMAs
+    // (k_tile_rb below).  History of this path at 1024 x 2048 -> 1024, us per launch: 62 (one buffer, loads behind a branch)
+    // -> 49 (prefetch distance 2, second LDS buffer) -> 38.7 (this form; the MFMA pipe alone needs 27.3): what the in-kernel
+    // stamps (tools/rb_stamp_probe.py) and leave-one-out builds showed on the way is noted at each piece.
     constexpr bool DB = FAST && TM == 1 && TN == 1;
     constexpr int BUF = (BM + BN) * LDK;
     __shared__ __attribute__((aligned(16))) float smem[BUF * (DB ? 2 : 1)];
@@ -273,10 +274,9 @@ __device__ __forceinline__ void linear_tile_body(
     const int n0 = bn * BN;
     // (Measured and dropped: static per-workgroup s_setprio levels cost 4 %, start-up staggering of
     // co-resident workgroups changed nothing, double-buffered LDS with one barrier per K-tile lost 5-10 % at
-    // Games-sized launches -- the second buffer costs a co-resident workgroup.  At batch-sized launches (1-4 k rows,
-    // about one workgroup per CU) neither prefetch distance 2 with two register sets nor that plus a second LDS buffer
-    // and one barrier per K-tile moved the time by more than 3 % either way, and 128 x 64 / 64 x 128 tiles were slower
-    // on all but the widest layer: those launches are 15-90 us and bound by their few K-chains per SIMD.)
+    // Games-sized launches of the multi-accumulator tiles -- the second buffer costs a co-resident workgroup -- and
+    // 128 x 64 / 64 x 128 tiles were slower than 64 x 64 at batch-sized launches on all but the widest layer.  A deeper
+    // global prefetch ring changes nothing: 2 / 4 / 6 register sets 47.9 / 47.2 / 48.0 us before the loads were spread.)
 
     LCREC_GMARK(0);
     f32x16 acc[TM][TN];
@@ -287,10 +287,9 @@ __device__ __forceinline__ void linear_tile_body(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // two register sets: the global loads of K-tile kt+2 are issued before K-tile kt's MFMAs (prefetch distance 2).
-    // rocprofv3 counters on the batch-sized launches (1024 x 2048 -> 1024: 256 workgroups, one per CU) showed where the
-    // time goes: MFMA busy 48 % of the kernel, 55 % of every wave's cycles in s_waitcnt, four fifths of that on vmcnt --
-    // one K-tile (16 KB per workgroup) in flight against a ~2 000-cycle loaded latency is Little's law, not arithmetic.
+    // (non-DB tiles) two register sets: the global loads of K-tile kt+2 are issued before K-tile kt's MFMAs (prefetch
+    // distance 2).  rocprofv3 counters on the batch-sized launches (1024 x 2048 -> 1024: 256 workgroups, one per CU) had shown
+    // MFMA busy 48 % of the kernel and 55 % of every wave's cycles in s_waitcnt, four fifths of that on vmcnt.
     StageRegs<BM> ra, ra2;
     StageRegs<BN> rw, rw2;
     // split K (backward dW only, where K is the batch and the output is small): workgroup (tile, blockIdx.y) runs the
@@ -553,27 +552,26 @@ __device__ __forceinline__ void linear_tile_body(
             constexpr int s = decltype(s_c)::value, g = s >> 2, q = s & 3;
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc.a[g][q], fc.w[g][q], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef LCREC_RB_EXP
-#define LCREC_RB_EXP 0
-#endif
-            if constexpr (s < 8) { if constexpr (LCREC_RB_EXP != 2) frag_read(fn, IntC<s>{}, cur ^ 1); }
-            if constexpr (s < 8 && (s & 1) == 0 && LCREC_RB_EXP != 4) load_piece(ra_free, rw_free, kt + LCREC_GEMM_RING + 1, live, IntC<s / 2>{});
-            else if constexpr ((s & 1) == 0 && LCREC_RB_EXP != 1) store_piece(ra_next, rw_next, cur, IntC<(s - 8) / 2>{});
+            // gap s carries: fragment read s (s < 8); load quarter s (s < 4); store quarter (s - 5) / 2 (s = 5, 7, 9, 11) -- the
+            // last LDS operation leaves four MFMAs before the wait.  Measured at 1024 x 2048 -> 1024: 38.7 us; loads in gaps
+            // 0, 2, 4, 6 and stores in 8 .. 14: 40.1; stores first (1 .. 7) and loads last (9 .. 15): 40.0.  Leaving out, one at a
+            // time, the reads / the barrier / the loads (wrong results, timing only): 36.9 / 38.3 / 36.1.
+            if constexpr (s < 8) frag_read(fn, IntC<s>{}, cur ^ 1);
+            if constexpr (s < 4) load_piece(ra_free, rw_free, kt + LCREC_GEMM_RING + 1, live, IntC<s>{});
+            if constexpr (s >= 5 && s <= 11 && (s & 1) == 1) store_piece(ra_next, rw_next, cur, IntC<(s - 5) / 2>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (s == 7) LCREC_GSTAMP(2);
         });
         LCREC_GSTAMP(3);
-        if constexpr (LCREC_RB_EXP != 5)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads and its stores
         LCREC_GSTAMP(4);
-        if constexpr (LCREC_RB_EXP != 3) __syncthreads();
+        __syncthreads();
         LCREC_GSTAMP(5);
     };
     if constexpr (DB) {
         // Global prefetch: a ring of RING register sets; K-tile kt0+j lives in set j % RING, is loaded RING-1 iterations
-        // before it is stored to LDS, i.e. RING-1 K-tiles (16 KB each) are in flight per workgroup.  With one workgroup per
-        // CU and every operand line a first touch at the chip's frontier (all workgroups walk K in step), the loaded
-        // latency is 1-2 us: two K-tiles in flight (the first form) cover ~0.9 us of MFMA work at best.
+        // before it is stored to LDS, i.e. RING-1 K-tiles (16 KB each) are in flight per workgroup.  (The depth turned out
+        // not to matter -- see above; 4 leaves slack for a slow first touch at no cost but 32 registers.)
         constexpr int RING = LCREC_GEMM_RING;
         static_assert(RING >= 2 && RING % 2 == 0, "the fragment sets alternate with the parity of the ring slot");
         Frag fa, fb;
