@@ -592,6 +592,9 @@ __device__ __forceinline__ void linear_tile_body(
             static_for<4>([&](auto p_c) { load_piece(sa[0], sw[0], kt0 + RING, kt0 + RING < nk, p_c); });
             __syncthreads();
             static_for<8>([&](auto s_c) { frag_read(fa, s_c, 0); });
+            // iteration 0 stores K-tile 2 into buffer 0: not before every wave has its fragments of K-tile 0 out of it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
         }
         LCREC_GMARK(1);
         for (int kt = kt0; kt < nk; kt += RING) {

@@ -953,6 +953,233 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same solve in SCALING form.  The reference's loop (layers.py:85-108) only ever multiplies whole rows and whole
+// columns of Q = exp(-d/eps): after any number of steps Q_ij = a_i E_ij b_j, and the two normalisations of an iteration are
+//     a_i = 1 / (B * sum_j E_ij b_j)          (Q /= Q.sum(1); Q /= B  -- the old a_i cancels, and so does the grand total)
+//     b_j = 1 / (K * sum_i a_i E_ij)          (Q /= Q.sum(0); Q /= K  -- the old b_j cancels)
+// with the final argmax over E_ij b_j (a_i and the trailing `Q *= B` are per-row constants).  E stays in registers untouched;
+// an iteration is two fused multiply-add sweeps and B + K divisions instead of 2 B K of them (16 per lane and iteration
+// before, 6.5 k of an iteration's 16-19 k cycles), no grand total and so no grid barrier, and with the arithmetic gone the rows
+// fit on 16 workgroups instead of 64-128, which makes the ONE-hop exchange cheap: every workgroup publishes its K column
+// partials (values are their own flags, three rotating buffers, exactly as above) and every workgroup adds all nblk of
+// them, in workgroup order, itself -- one store -> load trip through memory per iteration instead of two.
+// Values differ from the in-place form by rounding only (~1e-15 relative after 50 iterations); assignments can differ
+// where the two best entries of a row agree to that precision -- the tests' margin is 1e-9.  Exchange slots are armed by a
+// launch of their own (sk_arm_kernel) before this kernel, since nothing inside it orders "armed" before the first poll.
+// ------------------------------------------------------------------------------------------
+struct SkScale {
+    const float *d;        // [B][K] fp32 distances
+    double *part;          // [3][nblk][K] column partials
+    const unsigned *minmax;
+    unsigned *flag;        // set to 1 when a wait timed out
+    int64_t B;
+    int K, nblk, iters;
+    double eps;
+    int64_t *idx_out;
+    int64_t idx_stride;
+};
+
+__global__ __launch_bounds__(256) void sk_arm_kernel(double *slots, int64_t count)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<unsigned long long *>(slots)[i] = SKP_EMPTY;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)      // wave-uniform result (two v_readlane_b32)
+{
+    const unsigned long long bits = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)bits, src_lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(bits >> 32), src_lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+template <int CPL, int RW>
+__global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
+{
+    constexpr int ROWS = RW * SKP_WAVES;             // rows per workgroup
+    extern __shared__ __attribute__((aligned(16))) double sks_sm[];
+    const int K = p.K;
+    double *colacc = sks_sm;                          // [SKP_WAVES][K]; after the publish: the gather buffer [split][K]
+    double *bsh = sks_sm + (size_t)SKP_WAVES * K;     // [K] the new column scales
+    __shared__ int abort_sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS + wave * RW;
+    if (threadIdx.x == 0) abort_sh = 0;
+    bool gave_up = false;
+    const double Bd = (double)p.B, Kd = (double)K;
+    const float hi = ord2f(p.minmax[1]), lo = ord2f(p.minmax[0]);
+    const float middle = (hi + lo) / 2.0f;
+    const float amplitude = (hi - middle) + 1e-5f;
+
+    double e[RW][CPL], b[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) b[c] = 1.0;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            e[r][c] = 0.0;                            // rows past B and columns past K: zeros, they add nothing anywhere
+            if (row0 + r < p.B && j < K) {
+                const float cen = (p.d[(row0 + r) * K + j] - middle) / amplitude;
+                e[r][c] = exp(-(double)cen / p.eps);
+            }
+        }
+    const int split = K >= SKP_THREADS ? 1 : SKP_THREADS / K;        // threads per column in the gather (K a multiple of 64)
+    const int chunk = (p.nblk + split - 1) / split;
+    constexpr int LOG_RW = RW == 16 ? 4 : RW == 8 ? 3 : RW == 4 ? 2 : RW == 2 ? 1 : 0, LOWBITS = 6 - LOG_RW;
+    static_assert((1 << LOG_RW) == RW, "RW is a power of two");
+    const int my_row = lane >> LOWBITS;              // the row whose sum this lane ends up holding (see below)
+    __syncthreads();
+
+    for (int it = 0; it < p.iters; ++it) {
+        if (it >= 2) {                                           // re-arm the buffer of the NEXT iteration (it carried it - 2)
+            double *arm = p.part + ((size_t)((it + 1) % 3) * p.nblk + blockIdx.x) * K;
+            for (int j = threadIdx.x; j < K; j += SKP_THREADS) skp_put(arm + j, SKP_EMPTY);
+        }
+        // row scales a_i = 1 / (B * sum_j E_ij b_j).  The RW row sums of a wave are reduced TOGETHER: each exchange step halves
+        // the number of values a lane carries (the upper half of the lanes keeps the upper half of the rows), so RW - 1
+        // exchanges instead of 6 RW, after which lane l holds row (l >> LOWBITS)'s sum over its group of lanes; the remaining
+        // LOWBITS butterfly steps finish it.  Then ONE division sequence serves all rows (lane = row), and the scales come back
+        // as wave-uniform values by readlane.  (First form: RW butterflies and RW divisions per wave and iteration: 5.6 us per
+        // iteration at 8 rows per wave, 8.4 at 16.)
+        double s[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            s[r] = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) s[r] = fma(e[r][c], b[c], s[r]);
+        }
+        {
+            int o = 32;
+#pragma unroll
+            for (int n = RW / 2; n >= 1; n >>= 1, o >>= 1) {
+                const bool upper = (lane & o) != 0;
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    const double keep = upper ? s[i + n] : s[i];
+                    const double send = upper ? s[i] : s[i + n];
+                    s[i] = keep + __shfl_xor(send, o, 64);
+                }
+            }
+#pragma unroll
+            for (; o > 0; o >>= 1) s[0] += __shfl_xor(s[0], o, 64);
+        }
+        const double a_mine = row0 + my_row < p.B ? 1.0 / (Bd * s[0]) : 0.0;
+        double acc[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const double a = readlane_f64(a_mine, r << LOWBITS);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[c] = fma(a, e[r][c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            if (j < K) colacc[wave * K + j] = acc[c];
+        }
+        __syncthreads();
+        double *out = p.part + ((size_t)(it % 3) * p.nblk + blockIdx.x) * K;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the re-arming stores have reached memory
+        for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
+            double t = 0.0;
+            for (int w = 0; w < SKP_WAVES; ++w) t += colacc[w * K + j];
+            skp_put(out + j, __builtin_bit_cast(unsigned long long, t));
+        }
+        __syncthreads();                                         // colacc has been read: it is the gather buffer now
+        // every workgroup's partial of every column, added in workgroup order (chunk by chunk when several threads share a column)
+        const double *src = p.part + (size_t)(it % 3) * p.nblk * K;
+        for (int i = threadIdx.x; i < K * split; i += SKP_THREADS) {
+            const int j = i % K, h = i / K;
+            const int b0 = h * chunk, b1 = b0 + chunk < p.nblk ? b0 + chunk : p.nblk;
+            double t = 0.0;
+            for (int bb = b0; bb < b1; bb += 8) {                // eight polls in flight, then the adds in order
+                unsigned long long v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (bb + u < b1) v[u] = skp_peek(src + (size_t)(bb + u) * K + j);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (bb + u < b1) t += skp_take(src + (size_t)(bb + u) * K + j, v[u], p.flag, gave_up);
+            }
+            colacc[h * K + j] = t;
+        }
+        if (gave_up) abort_sh = 1;
+        __syncthreads();
+        for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
+            double t = 0.0;
+            for (int h = 0; h < split; ++h) t += colacc[h * K + j];
+            bsh[j] = 1.0 / (Kd * t);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            if (j < K) b[c] = bsh[j];
+        }
+        if (abort_sh) break;                                     // uniform: read after a barrier every thread passed
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        double best = -1.0;
+        int bj = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            if (row0 + r < p.B && j < K) {
+                const double v = e[r][c] * b[c];
+                if (v > best) { best = v; bj = j; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double b2 = __shfl_xor(best, o, 64);
+            const int j2 = __shfl_xor(bj, o, 64);
+            if (b2 > best || (b2 == best && j2 < bj)) { best = b2; bj = j2; }
+        }
+        if (lane == 0 && row0 + r < p.B) {
+            const unsigned bad = __hip_atomic_load(p.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.idx_out[(row0 + r) * p.idx_stride] = bad ? -1 : bj;
+        }
+    }
+}
+
+static size_t sks_lds_bytes(int K) { return (size_t)(SKP_WAVES + 1) * K * sizeof(double); }
+
+template <int CPL, int RW>
+static bool launch_sks(const SkScale &p, hipStream_t stream)
+{
+    // every workgroup must be resident (the hand-overs assume it): at most 64 of them, one per CU is always possible on an
+    // idle device; other work holding CUs is what the bounded spins are for
+    const size_t lds = sks_lds_bytes(p.K);
+    auto kern = sk_scaling_kernel<CPL, RW>;
+    if (lds > 48 * 1024) {
+        static thread_local size_t granted = 0;
+        if (granted < lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            granted = lds;
+        }
+    }
+    hipLaunchKernelGGL(sk_arm_kernel, dim3(64), dim3(256), 0, stream, p.part, (int64_t)3 * p.nblk * p.K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(SKP_THREADS), lds, stream, p);
+    return true;
+}
+
+template <int CPL>
+static bool launch_sks_rw(const SkScale &p, int rw, hipStream_t stream)
+{
+    if constexpr (CPL <= 4) { if (rw == 16) return launch_sks<CPL, 16>(p, stream); }
+    if constexpr (CPL <= 8) { if (rw == 8) return launch_sks<CPL, 8>(p, stream); }
+    if (rw == 4) return launch_sks<CPL, 4>(p, stream);
+    return launch_sks<CPL, 2>(p, stream);
+}
+
 static size_t skp_lds_bytes(int K, int nblk) { return ((size_t)(1 + SKP_WAVES) * K + nblk) * sizeof(double); }
 
 // Whether all `nblk` workgroups of sk_persistent_kernel<CPL, RW> can be resident at once on the current device: the
@@ -1021,6 +1248,31 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     if (iters == 0) return fail(LCREC_EUNSUPPORTED, "sinkhorn: iters must be >= 1");
     TraceScope trace(K_SINKHORN, stream);
 
+    // one launch, scaling form (sk_scaling_kernel): rows per workgroup 16 / 32 / 64 / 128 (RW = 2 .. 16 rows per wave, at most
+    // 64 doubles of E per lane), the smallest that needs no more than 16 workgroups -- fewer partials to add, and the arithmetic
+    // no longer wants more CUs.  LCREC_SINKHORN_SCALING=0: the in-place form below.
+    static const bool allow_scaling = [] { const char *e = getenv("LCREC_SINKHORN_SCALING"); return !e || atoi(e) != 0; }();
+    static const int nblk_target = [] { const char *e = getenv("LCREC_SK_BLOCKS"); return e ? atoi(e) : 16; }();
+    if (allow_scaling && K % 64 == 0 && K <= 1024) {
+        const int cpl_s = K / 64, cpl_t = cpl_s <= 1 ? 1 : cpl_s <= 2 ? 2 : cpl_s <= 4 ? 4 : cpl_s <= 8 ? 8 : 16;
+        const int rw_cap = cpl_t <= 4 ? 16 : (cpl_t <= 8 ? 8 : 4);
+        int rw = 2;
+        while (rw < rw_cap && (B + 8 * rw - 1) / (8 * rw) > nblk_target) rw *= 2;
+        const int64_t nblk_s = (B + 8 * rw - 1) / (8 * rw);
+        if (nblk_s <= 64 && 3 * nblk_s <= B) {                   // the exchange buffers live in the unused Q region ([B][K] doubles)
+            SkScale q;
+            q.d = d; q.part = p.Q; q.minmax = minmax; q.flag = minmax + 5;
+            q.B = B; q.K = K; q.nblk = (int)nblk_s; q.iters = iters; q.eps = eps;
+            q.idx_out = idx_out; q.idx_stride = idx_stride;
+            bool launched;
+            if (cpl_t == 1) launched = launch_sks_rw<1>(q, rw, stream);
+            else if (cpl_t == 2) launched = launch_sks_rw<2>(q, rw, stream);
+            else if (cpl_t == 4) launched = launch_sks_rw<4>(q, rw, stream);
+            else if (cpl_t == 8) launched = launch_sks_rw<8>(q, rw, stream);
+            else launched = launch_sks_rw<16>(q, rw, stream);
+            if (launched) return check_launch("sk_scaling_kernel");
+        }
+    }
     // one-launch register-resident path when every workgroup can be resident (see sk_persistent_kernel)
     const int cpl = (K + 63) / 64;
     // K = 256 (the reference's codebook size): two rows per wave instead of four when that still fits 128 workgroups
