@@ -967,6 +967,11 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
 // Values differ from the in-place form by rounding only (~1e-15 relative after 50 iterations); assignments can differ
 // where the two best entries of a row agree to that precision -- the tests' margin is 1e-9.  Exchange slots are armed by a
 // launch of their own (sk_arm_kernel) before this kernel, since nothing inside it orders "armed" before the first poll.
+// Measured, 1024 x 256, 50 iterations (rocprofv3 / in-kernel stamps, tools/sk_stamp_probe.py): in-place form 342 us, 16.4 k
+// cycles per iteration on 64 workgroups; this form 8.4 k cycles on 16 workgroups (175 us): the hand-over 3.1 k, row sums 1.6 k,
+// scales + column accumulation 1.0 k, publish 1.0 k, column scales 0.9 k, barriers and loop 0.9 k.  8 / 32 workgroups: the same
+// within 3 % (fewer partials to poll against more rows per wave).  The collision-group kernels keep the in-place form: their
+// assignments go into the index file, which is compared byte for byte with the reference's.
 // ------------------------------------------------------------------------------------------
 struct SkScale {
     const float *d;        // [B][K] fp32 distances
@@ -984,6 +989,43 @@ __global__ __launch_bounds__(256) void sk_arm_kernel(double *slots, int64_t coun
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
         reinterpret_cast<unsigned long long *>(slots)[i] = SKP_EMPTY;
+}
+
+// Cross-lane moves of a double without the LDS crossbar.  row_partner<LEV>: the value of the lane this one is paired with at
+// level LEV inside its row of 16 lanes -- an involution that flips lane bit LEV (3: row_mirror, 2: row_half_mirror, 1 / 0:
+// quad permutes), which is all a sum reduction needs.  swap16_sum / swap32_sum: v + (v of the lane 16 / 32 away), by the gfx950
+// v_permlane16_swap / v_permlane32_swap.
+template <int LEV>
+__device__ __forceinline__ double row_partner(double v)
+{
+    constexpr int CTRL = LEV == 3 ? 0x140 : LEV == 2 ? 0x141 : LEV == 1 ? 0x4E : 0xB1;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double swap16_sum(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u32x2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double swap32_sum(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u32x2 l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+// f(level 3, RW/2), f(level 2, RW/4), ...: the LOG halving levels of the row-sum reduction, as compile-time constants
+template <int N> struct SkInt { static constexpr int value = N; };
+template <int LOG, int I = 0, class F>
+__device__ __forceinline__ void static_for_levels(F &&f)
+{
+    if constexpr (I < LOG) {
+        f(SkInt<3 - I>{}, SkInt<((1 << LOG) >> (I + 1))>{});
+        static_for_levels<LOG, I + 1>(f);
+    }
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane)      // wave-uniform result (two v_readlane_b32)
@@ -1028,22 +1070,26 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
         }
     const int split = K >= SKP_THREADS ? 1 : SKP_THREADS / K;        // threads per column in the gather (K a multiple of 64)
     const int chunk = (p.nblk + split - 1) / split;
-    constexpr int LOG_RW = RW == 16 ? 4 : RW == 8 ? 3 : RW == 4 ? 2 : RW == 2 ? 1 : 0, LOWBITS = 6 - LOG_RW;
+    constexpr int LOG_RW = RW == 16 ? 4 : RW == 8 ? 3 : RW == 4 ? 2 : RW == 2 ? 1 : 0, LOWBITS = 4 - LOG_RW;
     static_assert((1 << LOG_RW) == RW, "RW is a power of two");
-    const int my_row = lane >> LOWBITS;              // the row whose sum this lane ends up holding (see below)
+    const int my_row = (lane & 15) >> LOWBITS;       // the row whose sum this lane ends up holding (see below)
     __syncthreads();
+    SK_STAMP_DECL;
 
     for (int it = 0; it < p.iters; ++it) {
+        SK_STAMP(7);
         if (it >= 2) {                                           // re-arm the buffer of the NEXT iteration (it carried it - 2)
             double *arm = p.part + ((size_t)((it + 1) % 3) * p.nblk + blockIdx.x) * K;
             for (int j = threadIdx.x; j < K; j += SKP_THREADS) skp_put(arm + j, SKP_EMPTY);
         }
-        // row scales a_i = 1 / (B * sum_j E_ij b_j).  The RW row sums of a wave are reduced TOGETHER: each exchange step halves
-        // the number of values a lane carries (the upper half of the lanes keeps the upper half of the rows), so RW - 1
-        // exchanges instead of 6 RW, after which lane l holds row (l >> LOWBITS)'s sum over its group of lanes; the remaining
-        // LOWBITS butterfly steps finish it.  Then ONE division sequence serves all rows (lane = row), and the scales come back
-        // as wave-uniform values by readlane.  (First form: RW butterflies and RW divisions per wave and iteration: 5.6 us per
-        // iteration at 8 rows per wave, 8.4 at 16.)
+        // row scales a_i = 1 / (B * sum_j E_ij b_j).  The RW row sums of a wave are reduced TOGETHER, in registers: inside each
+        // row of 16 lanes LOG_RW halving exchanges (lanes with the level's bit set keep the upper half of the values, the
+        // others the lower half: RW - 1 exchanges in all instead of 4 RW) leave lane l with the sum of value (l & 15) >> (4 -
+        // LOG_RW) over some of its row's lanes, plain butterflies finish the row, and two swaps across the four rows finish the
+        // wave.  All of it DPP row operations and the gfx950 permlane swaps: a ds_bpermute (what __shfl_xor compiles to) is a
+        // ~250-cycle round trip through the LDS crossbar, and the first form of this loop was a chain of them -- 3 100 of an
+        // iteration's 10 400 cycles at 8 rows per wave, 9 200 at 16.  Then ONE division sequence serves all rows (lane = row) and
+        // the scales come back as wave-uniform values by readlane.
         double s[RW];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
@@ -1051,21 +1097,22 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
 #pragma unroll
             for (int c = 0; c < CPL; ++c) s[r] = fma(e[r][c], b[c], s[r]);
         }
-        {
-            int o = 32;
+        static_for_levels<LOG_RW>([&](auto lev_c, auto n_c) {                // halving levels: lane bit 3, 2, ...
+            constexpr int LEV = decltype(lev_c)::value, n = decltype(n_c)::value;
+            const bool upper = (lane & (1 << LEV)) != 0;
 #pragma unroll
-            for (int n = RW / 2; n >= 1; n >>= 1, o >>= 1) {
-                const bool upper = (lane & o) != 0;
-#pragma unroll
-                for (int i = 0; i < n; ++i) {
-                    const double keep = upper ? s[i + n] : s[i];
-                    const double send = upper ? s[i] : s[i + n];
-                    s[i] = keep + __shfl_xor(send, o, 64);
-                }
+            for (int i = 0; i < n; ++i) {
+                const double keep = upper ? s[i + n] : s[i];
+                const double send = upper ? s[i] : s[i + n];
+                s[i] = keep + row_partner<LEV>(send);
             }
-#pragma unroll
-            for (; o > 0; o >>= 1) s[0] += __shfl_xor(s[0], o, 64);
-        }
+        });
+        if constexpr (LOG_RW < 4) s[0] += row_partner<3 - LOG_RW>(s[0]);     // the row's remaining levels: plain butterflies
+        if constexpr (LOG_RW < 3) s[0] += row_partner<2 - LOG_RW>(s[0]);
+        if constexpr (LOG_RW < 2) s[0] += row_partner<1 - LOG_RW>(s[0]);
+        s[0] = swap16_sum(s[0]);
+        s[0] = swap32_sum(s[0]);
+        SK_STAMP(0);
         const double a_mine = row0 + my_row < p.B ? 1.0 / (Bd * s[0]) : 0.0;
         double acc[CPL];
 #pragma unroll
@@ -1082,6 +1129,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
             if (j < K) colacc[wave * K + j] = acc[c];
         }
         __syncthreads();
+        SK_STAMP(1);
         double *out = p.part + ((size_t)(it % 3) * p.nblk + blockIdx.x) * K;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the re-arming stores have reached memory
         for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
@@ -1090,6 +1138,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
             skp_put(out + j, __builtin_bit_cast(unsigned long long, t));
         }
         __syncthreads();                                         // colacc has been read: it is the gather buffer now
+        SK_STAMP(2);
         // every workgroup's partial of every column, added in workgroup order (chunk by chunk when several threads share a column)
         const double *src = p.part + (size_t)(it % 3) * p.nblk * K;
         for (int i = threadIdx.x; i < K * split; i += SKP_THREADS) {
@@ -1108,7 +1157,9 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
             colacc[h * K + j] = t;
         }
         if (gave_up) abort_sh = 1;
+        SK_STAMP(3);
         __syncthreads();
+        SK_STAMP(4);
         for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
             double t = 0.0;
             for (int h = 0; h < split; ++h) t += colacc[h * K + j];
@@ -1120,6 +1171,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
             const int j = lane + 64 * c;
             if (j < K) b[c] = bsh[j];
         }
+        SK_STAMP(5);
         if (abort_sh) break;                                     // uniform: read after a barrier every thread passed
     }
 #pragma unroll

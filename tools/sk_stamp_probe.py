@@ -14,6 +14,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lcrec_amd import _lib, ops  # noqa: E402
 
+SCALING = ["row sums E b, reduced together", "row scales (1 division), column accumulation, LDS", "8-wave sums -> global (publish)",
+           "gather: poll + add all workgroups' partials (thread 0's share)", "barrier after the gather (slowest thread)",
+           "column scales (1 division) + barrier", "(unused)", "(loop back, re-arm)"]
 PHASES = ["row/col normalise + LDS partials", "partials -> global (A)", "owner gathers its columns (B: poll + load)", "owner adds + stores sums",
           "(unused)", "(unused)", "all sums (C: poll + load)", "(loop back)"]
 
@@ -46,7 +49,8 @@ def main():
     n = a.reps * a.iters
     print(f"rows {a.rows} codes {a.codes}: {e0.elapsed_time(e1) / a.reps * 1e3:.1f} us per solve (distances + solve, stamped build)")
     tot = sum(buf)
-    for name, c in zip(PHASES, buf):
+    scaling = os.environ.get("LCREC_SINKHORN_SCALING", "1") != "0" and a.codes % 64 == 0
+    for name, c in zip(SCALING if scaling else PHASES, buf):
         print(f"  {name:45s} {c / n:9.0f} cycles/iteration  {100.0 * c / tot:5.1f} %")
     print(f"  {'sum':45s} {tot / n:9.0f} cycles/iteration (s_memtime ticks)")
 
