@@ -224,12 +224,23 @@ def linear_backward_splits(n, in_dim, out_dim):
 def flatten_codebooks(codebooks):
     """List of [K_l, e] tensors -> (flat fp32 tensor, [K_l]) in the layout lcrec_rq_assign expects."""
     ks = [int(c.shape[0]) for c in codebooks]
-    flat = torch.cat([_dev(c, "codebook").reshape(-1) for c in codebooks])
+    cbs = [_dev(c, "codebook") for c in codebooks]
+    # codebooks that already lie back to back in ONE storage (the training engine's flat parameter buffer) are passed as a
+    # view of it: no concatenation launch per step.  Every tensor must belong to that storage and the view must fit in it --
+    # separately allocated parameters can be neighbours in memory too, and a view past the end of a storage resizes it.
+    base = cbs[0].untyped_storage()
+    total = sum(c.numel() for c in cbs)
+    if (len(cbs) > 1 and all(c.untyped_storage().data_ptr() == base.data_ptr() for c in cbs)
+            and all(a.data_ptr() + a.numel() * 4 == b.data_ptr() for a, b in zip(cbs, cbs[1:]))
+            and (cbs[0].storage_offset() + total) * 4 <= base.nbytes()):
+        flat = cbs[0].new_empty(0).set_(base, cbs[0].storage_offset(), (total,), (1,))
+        return flat, ks
+    flat = cbs[0].reshape(-1) if len(cbs) == 1 else torch.cat([c.reshape(-1) for c in cbs])
     return flat, ks
 
 
 def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=False, xq_init=None, audit=None,
-              tie_tau=None):
+              tie_tau=None, sse_out=None):
     """ResidualVectorQuantizer.forward values with use_sk=False (rq.py:39-55).
 
     xq_init: optional [n, e] tensor that the x_q sum starts from (it is updated in place and returned).
@@ -250,7 +261,7 @@ def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=F
             raise _lib.LcrecError("xq_init must be a contiguous [n, e] float32 device tensor")
     else:
         xq = torch.empty((n, e), dtype=torch.float32, device=dev) if want_xq else None
-    sse = torch.zeros(L, dtype=torch.float64, device=dev) if want_sse else None
+    sse = _sse_buffer(sse_out, L, dev, n) if want_sse else None
     resid = torch.empty((L + 1, n, e), dtype=torch.float32, device=dev) if want_resid else None
     margin, neartie, tau = _audit_buffers(audit, tie_tau, n, L, dev)
     karr = _ints(ks)
@@ -343,7 +354,9 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
         # grid barrier ever times out; turn that into an error rather than training on garbage --
         # here and now, or (inside deferred_checks(), the trainer's epoch loop) when the block ends,
         # so that a training step has no host synchronisation of its own
-        bad = (out < 0).any()
+        # (a single problem: the kernel poisons EVERY row -- whoever timed out set the flag all workgroups read before they
+        # write -- so the first row tells; several groups: only the rows of the group that took that path)
+        bad = (out[0] < 0) if G == 1 else (out < 0).any()
         if _deferred is not None:
             _deferred.append(("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "
                               "set LCREC_SINKHORN_PERSISTENT=0 to use the multi-launch solver", bad))
@@ -399,7 +412,19 @@ class deferred_checks:
         return False
 
 
-def rq_apply_level(resid, codebook, idx, xq=None, want_sse=False):
+def _sse_buffer(sse_out, L, dev, n=1):
+    """float64 [L] for a kernel's per-level sums of squares: the caller's view (a slice of its own buffer) or a new one.
+    The kernels write every slot, so there is no zero fill -- except for an empty batch, which launches nothing."""
+    if sse_out is None:
+        return (torch.zeros if n == 0 else torch.empty)(L, dtype=torch.float64, device=dev)
+    if not (sse_out.is_cuda and sse_out.dtype == torch.float64 and sse_out.is_contiguous() and sse_out.numel() == L):
+        raise _lib.LcrecError(f"sse_out must be a contiguous float64 [{L}] device tensor")
+    if n == 0:
+        sse_out.zero_()
+    return sse_out
+
+
+def rq_apply_level(resid, codebook, idx, xq=None, want_sse=False, sse_out=None):
     """Gather + STE + residual update of one level for given indices (vq.py:87-95, rq.py:47-48).
 
     xq: None (start a new x_q sum) or the running [n, e] sum, updated in place.
@@ -416,7 +441,7 @@ def rq_apply_level(resid, codebook, idx, xq=None, want_sse=False):
     elif not (xq.is_cuda and xq.is_contiguous() and xq.dtype == torch.float32 and tuple(xq.shape) == (n, e)):
         raise _lib.LcrecError("xq must be a contiguous [n, e] float32 device tensor")
     nxt = torch.empty_like(resid)
-    sse = torch.zeros(1, dtype=torch.float64, device=resid.device) if want_sse else None
+    sse = _sse_buffer(sse_out, 1, resid.device, n) if want_sse else None
     with _on(resid.device):
         ws = _workspace(8192, resid.device)
         rc = lib.lcrec_rq_apply_level(_ptr(resid), n, e, _ptr(codebook), K, _ptr(idx), stride, _ptr(xq),

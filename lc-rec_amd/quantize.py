@@ -25,7 +25,7 @@ def quantize_values(zc, cbs, beta, plan, want_stats, training, want_code_grads=T
     L = len(cbs)
     dev = zc.device
     idx = torch.empty((n, L), dtype=torch.int64, device=dev)
-    sse = torch.zeros(L, dtype=torch.float64, device=dev)
+    sse = torch.empty(L, dtype=torch.float64, device=dev)      # every level's kernel writes its slot
     resid_in = [None] * L
     r, xq, l = zc, None, 0
     while l < L:
@@ -39,17 +39,16 @@ def quantize_values(zc, cbs, beta, plan, want_stats, training, want_code_grads=T
             else:
                 ops.sinkhorn_assign(r, cbs[l], eps, iters, out=idx[:, l])
             resid_in[l] = r
-            xq, r, s = ops.rq_apply_level(r, cbs[l], idx[:, l], xq=xq, want_sse=True)
-            sse[l] = s[0]
+            xq, r, _ = ops.rq_apply_level(r, cbs[l], idx[:, l], xq=xq, want_sse=True, sse_out=sse[l:l + 1])
             l += 1
             continue
         m = l
         while m < L and plan[m] is None:
             m += 1
         flat, ks = ops.flatten_codebooks(cbs[l:m])
-        ridx, xq, rsse, resid = ops.rq_assign(r, flat, ks, want_xq=True, want_sse=True, want_resid=True, xq_init=xq)
+        ridx, xq, _, resid = ops.rq_assign(r, flat, ks, want_xq=True, want_sse=True, want_resid=True, xq_init=xq,
+                                           sse_out=sse[l:m])
         idx[:, l:m] = ridx
-        sse[l:m] = rsse
         for t in range(l, m):
             resid_in[t] = resid[t - l]
         r = resid[m - l]

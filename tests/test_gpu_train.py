@@ -120,6 +120,26 @@ def test_sharded_batchnorm_kernels_give_the_whole_batch_result(hip, cuts, feat, 
         np.testing.assert_allclose(torch.cat([p[1] for p in parts]).cpu().numpy(), out.grad.numpy(), rtol=1e-6, atol=1e-12)
 
 
+def test_flatten_codebooks_aliases_one_storage_only(hip):
+    """ops.flatten_codebooks hands lcrec_rq_assign a view when the codebooks lie back to back in ONE storage (the training
+    engine's flat parameter buffer) and a copy otherwise -- in particular for separately allocated parameters that happen to
+    be neighbours in memory: a view past the end of the first one's storage would resize it (move the parameter)."""
+    dev = torch.device(DEV)
+    a, b = torch.randn(32, 32, device=dev), torch.randn(32, 32, device=dev)       # two allocations, usually adjacent
+    size, ptr = a.untyped_storage().nbytes(), a.data_ptr()
+    flat, ks = hip.ops.flatten_codebooks([a, b])
+    assert ks == [32, 32] and torch.equal(flat, torch.cat([a.reshape(-1), b.reshape(-1)]))
+    assert a.untyped_storage().nbytes() == size and a.data_ptr() == ptr and flat.data_ptr() != ptr
+    buf = torch.randn(3 * 1024, device=dev)
+    v = [buf[i * 1024:(i + 1) * 1024].view(32, 32) for i in range(3)]
+    flat, _ = hip.ops.flatten_codebooks(v[:2])
+    assert flat.data_ptr() == v[0].data_ptr() and torch.equal(flat, buf[:2048]) and buf.untyped_storage().nbytes() == 3 * 4096
+    flat, _ = hip.ops.flatten_codebooks(v[1:])
+    assert flat.data_ptr() == v[1].data_ptr() and torch.equal(flat, buf[1024:])
+    flat, _ = hip.ops.flatten_codebooks([v[0], v[2]])                                # same storage, not neighbours: a copy
+    assert flat.data_ptr() != v[0].data_ptr() and torch.equal(flat, torch.cat([buf[:1024], buf[2048:]]))
+
+
 def test_relu_bias_backward_and_losses_match_torch(hip):
     rs = _rs(11)
     dev = torch.device(DEV)
