@@ -248,7 +248,7 @@ __device__ __forceinline__ void linear_tile_body(
     // (k_tile_rb below).  History of this path at 1024 x 2048 -> 1024, us per launch: 62 (one buffer, loads behind a branch)
     // -> 49 (prefetch distance 2, second LDS buffer) -> 38.7 (this form; the MFMA pipe alone needs 27.3): what the in-kernel
     // stamps (tools/rb_stamp_probe.py) and leave-one-out builds showed on the way is noted at each piece.
-    constexpr bool DB = FAST && TM == 1 && TN == 1;
+    constexpr bool DB = FAST && (TM * TN == 1 || (TM * TN == 2 && WAVES_M == 2));
     constexpr int BUF = (BM + BN) * LDK;
     __shared__ __attribute__((aligned(16))) float smem[BUF * (DB ? 2 : 1)];
     float *const As = smem, *const Ws = smem + BM * LDK;
@@ -449,7 +449,7 @@ __device__ __forceinline__ void linear_tile_body(
     // per CU -- and the stores in one block after the fourth MFMA, where the in-order wave stalled on the LDS queue: 1 770
     // cycles per K-tile against the MFMA pipe's 1 024.)  Stores and loads are unconditional (a K-tile past the end is
     // zeros from an out-of-range load; nobody multiplies it), so there is no branch for the waitcnt bookkeeping to merge.
-    struct Frag { f32x4 a[4], w[4]; };
+    struct Frag { f32x4 a[TM][4], w[TN][4]; };
     // A K-MAJOR operand (TA / TB: the backward products) keeps its LDS image k-major too in this form: [32 k][ROWS], no
     // padding.  Its global loads are 16 bytes = four rows of one k, so a K-tile goes to LDS with one conflict-free
     // ds_write_b128 per load (row-major image: four rows 36 floats apart per load, 16 r4 + 4 i + slot mod 32 -- the 32 lanes
@@ -458,21 +458,24 @@ __device__ __forceinline__ void linear_tile_body(
     // consecutive dwords, and the compiler pairs them into ds_read2st64_b32.  No de-interleaving: k is the address.
     const float *ak_base = As + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
     const float *wk_base = Ws + (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+    constexpr int NREAD = 4 * (TM + TN);              // fragment reads per K-tile: 32 rows x 8 k each, A's first
     auto frag_read = [&](Frag &f, auto slot_c, int buf) {
         constexpr int slot = decltype(slot_c)::value, g = slot & 3;
-        if constexpr (slot < 4) {
+        if constexpr (slot < 4 * TM) {
+            constexpr int i = slot >> 2;
             if constexpr (TA) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f.a[g][q] = ak_base[buf * BUF + (8 * g + 2 * q) * BM];
+                for (int q = 0; q < 4; ++q) f.a[i][g][q] = ak_base[buf * BUF + (8 * g + 2 * q) * BM + i * 32];
             } else {
-                f.a[g] = *reinterpret_cast<const f32x4 *>(a_base + buf * BUF + g * 8);
+                f.a[i][g] = *reinterpret_cast<const f32x4 *>(a_base + buf * BUF + i * 32 * LDK + g * 8);
             }
         } else {
+            constexpr int j = (slot - 4 * TM) >> 2;
             if constexpr (TB) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f.w[g][q] = wk_base[buf * BUF + (8 * g + 2 * q) * BN];
+                for (int q = 0; q < 4; ++q) f.w[j][g][q] = wk_base[buf * BUF + (8 * g + 2 * q) * BN + j * 32];
             } else {
-                f.w[g] = *reinterpret_cast<const f32x4 *>(w_base + buf * BUF + g * 8);
+                f.w[j][g] = *reinterpret_cast<const f32x4 *>(w_base + buf * BUF + j * 32 * LDK + g * 8);
             }
         }
     };
@@ -548,15 +551,17 @@ __device__ __forceinline__ void linear_tile_body(
         LCREC_GSTAMP(0);
         const bool live = kt + LCREC_GEMM_RING + 1 < nk;
         LCREC_GSTAMP(1);
-        static_for<16>([&](auto s_c) {
-            constexpr int s = decltype(s_c)::value, g = s >> 2, q = s & 3;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc.a[g][q], fc.w[g][q], acc[0][0], 0, 0, 0);
+        static_for<16 * TM * TN>([&](auto s_c) {
+            // MFMA s of the K-tile: k-step (g, q) outermost, then the wave's accumulators -- each accumulator's chain runs over k
+            // ascending, and with two of them consecutive MFMAs are independent
+            constexpr int s = decltype(s_c)::value, j = s % TN, i = (s / TN) % TM, kq = s / (TN * TM), g = kq >> 2, q = kq & 3;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc.a[i][g][q], fc.w[j][g][q], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // gap s carries: fragment read s (s < 8); load quarter s (s < 4); store quarter (s - 5) / 2 (s = 5, 7, 9, 11) -- the
-            // last LDS operation leaves four MFMAs before the wait.  Measured at 1024 x 2048 -> 1024: 38.7 us; loads in gaps
-            // 0, 2, 4, 6 and stores in 8 .. 14: 40.1; stores first (1 .. 7) and loads last (9 .. 15): 40.0.  Leaving out, one at a
-            // time, the reads / the barrier / the loads (wrong results, timing only): 36.9 / 38.3 / 36.1.
-            if constexpr (s < 8) frag_read(fn, IntC<s>{}, cur ^ 1);
+            // gap s carries: fragment read s (s < NREAD); load quarter s (s < 4); store quarter (s - 5) / 2 (s = 5, 7, 9, 11) -- the
+            // last LDS operation leaves at least four MFMAs before the wait.  Measured at 1024 x 2048 -> 1024 (64 x 64 tile):
+            // 38.7 us; loads in gaps 0, 2, 4, 6 and stores in 8 .. 14: 40.1; stores first (1 .. 7) and loads last (9 .. 15): 40.0.
+            // Leaving out, one at a time, the reads / the barrier / the loads (wrong results, timing only): 36.9 / 38.3 / 36.1.
+            if constexpr (s < NREAD) frag_read(fn, IntC<s>{}, cur ^ 1);
             if constexpr (s < 4) load_piece(ra_free, rw_free, kt + LCREC_GEMM_RING + 1, live, IntC<s>{});
             if constexpr (s >= 5 && s <= 11 && (s & 1) == 1) store_piece(ra_next, rw_next, cur, IntC<(s - 5) / 2>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -591,7 +596,7 @@ __device__ __forceinline__ void linear_tile_body(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             static_for<4>([&](auto p_c) { load_piece(sa[0], sw[0], kt0 + RING, kt0 + RING < nk, p_c); });
             __syncthreads();
-            static_for<8>([&](auto s_c) { frag_read(fa, s_c, 0); });
+            static_for<NREAD>([&](auto s_c) { frag_read(fa, s_c, 0); });
             // iteration 0 stores K-tile 2 into buffer 0: not before every wave has its fragments of K-tile 0 out of it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1395,6 +1400,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     reinterpret_cast<f32x4 *>(out)[q] = acc;
 }
 
+// a batch-sized launch (fewer than 512 tiles of 128 x 128) whose 64 x 128 tiles still give every CU one
+static bool wide_tiles_fill(int64_t M, int N) { return ((M + 63) / 64) * ((N + 127) / 128) >= 256; }
+
 // C[M][N] = A * B with A given [M][K] (TA false) or [K][M] (TA true) and B given [K][N] (always k-major here):
 // the two backward products of a Linear layer.  Same tiles and the same dispatch by (M, N) as the forward launches;
 // `splits` > 1 cuts K into that many runs of K-tiles whose partial products go to `partial` [splits][M][N].
@@ -1420,10 +1428,10 @@ static int launch_kmajor(const float *A, const float *B, int64_t M, int N, int K
     return check_launch("linear_fwd_kernel (k-major operands)");
 }
 
-// which tile shape a (M, N) output gets: 0 = 64x64, 1 = 128x128, 2 = 128x64, 3 = 128x32 (the forward rule)
+// which tile shape a (M, N) output gets: 0 = 64x64, 1 = 128x128, 2 = 128x64, 3 = 128x32, 4 = 64x128 (the forward rule)
 static int kmajor_shape(int64_t M, int N)
 {
-    if (N > 64) return ((M + 127) / 128) * ((N + 127) / 128) < 512 ? 0 : 1;
+    if (N > 64) return ((M + 127) / 128) * ((N + 127) / 128) >= 512 ? 1 : (wide_tiles_fill(M, N) ? 4 : 0);
     return N > 32 ? 2 : 3;
 }
 
@@ -1435,6 +1443,7 @@ static int gemm_kmajor(const float *A, const float *B, int64_t M, int N, int K, 
     case 0: return launch_kmajor<2, 2, 1, 1, TA>(A, B, M, N, K, C, splits, partial, stream);
     case 1: return launch_kmajor<2, 2, 2, 2, TA>(A, B, M, N, K, C, splits, partial, stream);
     case 2: return launch_kmajor<4, 1, 1, 2, TA>(A, B, M, N, K, C, splits, partial, stream);
+    case 4: return launch_kmajor<2, 2, 1, 2, TA>(A, B, M, N, K, C, splits, partial, stream);
     default: return launch_kmajor<4, 1, 1, 1, TA>(A, B, M, N, K, C, splits, partial, stream);
     }
 }
@@ -1615,6 +1624,10 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
         static const int small_tile = [] { const char *e = getenv("LCREC_GEMM_SMALL"); return e ? atoi(e) : 0; }();   // tuning only
         if (tiles128 < 512 && small_tile == 1) return launch_linear<2, 2, 1, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
         if (tiles128 < 512 && small_tile == 2) return launch_linear<2, 2, 2, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
+        // ... and 64 x 128 tiles (two accumulators per wave: a K-tile's fixed costs are paid once per 32 MFMAs instead of 16)
+        // when those still fill the chip: 768 -> 2048 at batch 2048 72 -> 62 us, 4096 -> 2048 at batch 1024 148 -> 144 us
+        if (tiles128 < 512 && small_tile == 0 && wide_tiles_fill(n, out_dim))
+            return launch_linear<2, 2, 1, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
         if (tiles128 < 512) return launch_linear<2, 2, 1, 1>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
         return launch_linear<2, 2, 2, 2>(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, stream);
     }
