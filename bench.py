@@ -286,7 +286,7 @@ def main():
         if out <= 32:
             return [("linear_fwd_128x32", rows)]
         if out <= 64:
-            return [("linear_fwd_128x64", rows)]
+            return [("linear_fwd_64x64" if -(-rows // 128) < 256 else "linear_fwd_128x64", rows)]
         ntile = -(-out // 128)
         pp_tiles = -(-rows // 256) * ntile
         rounds = -(-pp_tiles // 256)
