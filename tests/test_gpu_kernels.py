@@ -246,7 +246,9 @@ def _ref_sinkhorn_idx(z, cb, eps, iters):
 
 
 @pytest.mark.parametrize("B,K,e", [(2048, 256, 32), (1000, 256, 32), (256, 256, 32), (300, 100, 16), (4096, 1024, 32), (1000, 1024, 32),
-                                   (130, 256, 64)])
+                                   (130, 256, 64),
+                                   # every (columns per lane, rows per wave) form of the scaling-form solver: K = 64 .. 1024
+                                   (500, 64, 32), (700, 128, 16), (1500, 512, 32), (3000, 256, 32), (600, 512, 32), (333, 192, 32)])
 def test_sinkhorn_training_batch(hip, B, K, e):
     rs = _rs(B + K)
     z = rs.standard_normal((B, e)).astype(np.float32)
