@@ -48,7 +48,9 @@ def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
 
 
 @pytest.mark.parametrize("n,k,out", [(2048, 768, 2048), (475, 128, 64), (1000, 64, 32), (300, 2048, 1024), (77, 32, 128),
-                                     (2048, 36, 96), (1, 64, 32)])
+                                     (2048, 36, 96), (1, 64, 32),
+                                     (1024, 1024, 2048),      # dW [2048, 1024]: 64 x 128 tiles, both operands k-major
+                                     (1000, 2048, 512)])      # dX [1000, 2048]: 64 x 128 tiles, ragged rows
 def test_linear_backward_bit_exact(hip, oracle, n, k, out):
     """lcrec_linear_backward (k-major operand staging, no transposed copies) against the oracle's restatement
     on explicitly transposed operands: gx = gy W one fma chain per output; gw = gy^T x as the ordered sum of
