@@ -579,7 +579,11 @@ static int strip_cols(int F)
     static const int forced = [] { const char *e = getenv("LCREC_STRIP_COLS"); return e ? atoi(e) : 0; }();   // tuning only
     if (forced == 8 || forced == 16 || forced == 32) return forced;
     if (forced == -1) return F >= 4096 ? 32 : (F >= 2048 ? 16 : 8);
-    return F >= 1024 ? 32 : (F >= 256 ? 16 : 8);
+    // measured again after the step had become GPU-bound (batch 1024, ms per step at 768-d / 4096-d): this table's
+    // predecessor (32 from 1024 columns, 16 from 256, else 8) 1.259 / 1.848, 8 everywhere 1.293 / 1.920, 32 everywhere
+    // 1.354 / 1.929, 16 everywhere 1.241 / 1.839
+    (void)F;
+    return 16;
 }
 #define LCREC_STRIP_LAUNCH(KERN, F, stream, ...)                                                                      \
     do {                                                                                                              \
