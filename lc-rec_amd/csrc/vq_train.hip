@@ -1226,7 +1226,7 @@ static bool launch_sks(const SkScale &p, hipStream_t stream)
 template <int CPL>
 static bool launch_sks_rw(const SkScale &p, int rw, hipStream_t stream)
 {
-    if constexpr (CPL <= 4) { if (rw == 16) return launch_sks<CPL, 16>(p, stream); }
+    if constexpr (CPL > 1 && CPL <= 4) { if (rw == 16) return launch_sks<CPL, 16>(p, stream); }
     if constexpr (CPL <= 8) { if (rw == 8) return launch_sks<CPL, 8>(p, stream); }
     if (rw == 4) return launch_sks<CPL, 4>(p, stream);
     return launch_sks<CPL, 2>(p, stream);
@@ -1307,7 +1307,7 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     static const int nblk_target = [] { const char *e = getenv("LCREC_SK_BLOCKS"); return e ? atoi(e) : 16; }();
     if (allow_scaling && K % 64 == 0 && K <= 1024) {
         const int cpl_s = K / 64, cpl_t = cpl_s <= 1 ? 1 : cpl_s <= 2 ? 2 : cpl_s <= 4 ? 4 : cpl_s <= 8 ? 8 : 16;
-        const int rw_cap = cpl_t <= 4 ? 16 : (cpl_t <= 8 ? 8 : 4);
+        const int rw_cap = cpl_t == 1 ? 8 : cpl_t <= 4 ? 16 : (cpl_t <= 8 ? 8 : 4);   // (<1, 16> spills: not instantiated)
         int rw = 2;
         while (rw < rw_cap && (B + 8 * rw - 1) / (8 * rw) > nblk_target) rw *= 2;
         const int64_t nblk_s = (B + 8 * rw - 1) / (8 * rw);
