@@ -966,7 +966,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_persistent_kernel(SkPersist p)
 // them, in workgroup order, itself -- one store -> load trip through memory per iteration instead of two.
 // Values differ from the in-place form by rounding only (~1e-15 relative after 50 iterations); assignments can differ
 // where the two best entries of a row agree to that precision -- the tests' margin is 1e-9.  Exchange slots are armed by a
-// launch of their own (sk_arm_kernel) before this kernel, since nothing inside it orders "armed" before the first poll.
+// launch before this kernel (sk_ctrl_init_kernel, with the control words), since nothing inside it orders "armed" before the first poll.
 // Measured, 1024 x 256, 50 iterations (rocprofv3 / in-kernel stamps, tools/sk_stamp_probe.py): in-place form 342 us, 16.4 k
 // cycles per iteration on 64 workgroups; this form 8.4 k cycles on 16 workgroups (175 us): the hand-over 3.1 k, row sums 1.6 k,
 // scales + column accumulation 1.0 k, publish 1.0 k, column scales 0.9 k, barriers and loop 0.9 k.  8 / 32 workgroups: the same
@@ -984,12 +984,6 @@ struct SkScale {
     int64_t *idx_out;
     int64_t idx_stride;
 };
-
-__global__ __launch_bounds__(256) void sk_arm_kernel(double *slots, int64_t count)
-{
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
-        reinterpret_cast<unsigned long long *>(slots)[i] = SKP_EMPTY;
-}
 
 // Cross-lane moves of a double without the LDS crossbar.  row_partner<LEV>: the value of the lane this one is paired with at
 // level LEV inside its row of 16 lanes -- an involution that flips lane bit LEV (3: row_mirror, 2: row_half_mirror, 1 / 0:
@@ -1218,7 +1212,6 @@ static bool launch_sks(const SkScale &p, hipStream_t stream)
             granted = lds;
         }
     }
-    hipLaunchKernelGGL(sk_arm_kernel, dim3(64), dim3(256), 0, stream, p.part, (int64_t)3 * p.nblk * p.K);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(SKP_THREADS), lds, stream, p);
     return true;
 }
@@ -1269,9 +1262,13 @@ static bool launch_skp(const SkPersist &p, hipStream_t stream)
     return true;
 }
 
-__global__ void sk_ctrl_init_kernel(unsigned *ctrl)
+// control words {ord(min) = 0xffffffff, ord(max) = 0, -, -, barrier counter = 0, timeout flag = 0} and, for the scaling-form
+// solver, the sentinels of its exchange slots (`count` doubles; nothing inside that kernel orders "armed" before the first poll)
+__global__ __launch_bounds__(256) void sk_ctrl_init_kernel(unsigned *ctrl, double *slots, int64_t count)
 {
-    if (threadIdx.x < 8) ctrl[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 8) ctrl[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<unsigned long long *>(slots)[i] = SKP_EMPTY;
 }
 
 static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K, double eps, int iters,
@@ -1290,40 +1287,40 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     ws += align_up((size_t)nblk * sizeof(double), 256);
     unsigned *minmax = reinterpret_cast<unsigned *>(ws);
     p.d = d; p.minmax = minmax; p.B = B; p.K = K; p.nblk = (int)nblk; p.eps = eps;
-    // {ord(min) = 0xffffffff, ord(max) = 0, barrier counter = 0, timeout flag = 0}
-    // by a kernel, not by memset nodes: inside a captured hipGraph (engine.py) the two memsets were seen to take effect
-    // late -- replays found the previous solve's flag / a counter reset under a running barrier
-    hipLaunchKernelGGL(sk_ctrl_init_kernel, dim3(1), dim3(64), 0, stream, minmax);
+    // one launch, scaling form (sk_scaling_kernel): rows per workgroup 16 / 32 / 64 / 128 (RW = 2 .. 16 rows per wave, at most
+    // 64 doubles of E per lane), the smallest that needs no more than 16 workgroups -- fewer partials to add, and the arithmetic
+    // no longer wants more CUs.  LCREC_SINKHORN_SCALING=0: the in-place form below.
+    static const bool allow_scaling = [] { const char *e = getenv("LCREC_SINKHORN_SCALING"); return !e || atoi(e) != 0; }();
+    static const int nblk_target = [] { const char *e = getenv("LCREC_SK_BLOCKS"); return e ? atoi(e) : 16; }();
+    const int cpl_s = K / 64, cpl_t = cpl_s <= 1 ? 1 : cpl_s <= 2 ? 2 : cpl_s <= 4 ? 4 : cpl_s <= 8 ? 8 : 16;
+    const int rw_cap = cpl_t == 1 ? 8 : cpl_t <= 4 ? 16 : (cpl_t <= 8 ? 8 : 4);       // (<1, 16> spills: not instantiated)
+    int rw = 2;
+    while (rw < rw_cap && (B + 8 * rw - 1) / (8 * rw) > nblk_target) rw *= 2;
+    const int64_t nblk_s = (B + 8 * rw - 1) / (8 * rw);
+    // (the exchange buffers live in the Q region, [B][K] doubles, which this path does not use otherwise)
+    const bool scaling = allow_scaling && iters >= 1 && K % 64 == 0 && K <= 1024 && nblk_s <= 64 && 3 * nblk_s <= B;
+    // control words (and the scaling form's slot sentinels) by a kernel, not by memset nodes: inside a captured hipGraph
+    // (engine.py) the two memsets were seen to take effect late -- replays found the previous solve's flag / a counter reset
+    // under a running barrier
+    hipLaunchKernelGGL(sk_ctrl_init_kernel, dim3(scaling ? 64 : 1), dim3(256), 0, stream, minmax, p.Q, scaling ? (int64_t)3 * nblk_s * K : (int64_t)0);
     if (int rc0 = check_launch("sk_ctrl_init_kernel")) return rc0;
     int rc = vq_distances(r, B, e, cb, K, d, minmax, stream);
     if (rc) return rc;
     if (iters == 0) return fail(LCREC_EUNSUPPORTED, "sinkhorn: iters must be >= 1");
     TraceScope trace(K_SINKHORN, stream);
 
-    // one launch, scaling form (sk_scaling_kernel): rows per workgroup 16 / 32 / 64 / 128 (RW = 2 .. 16 rows per wave, at most
-    // 64 doubles of E per lane), the smallest that needs no more than 16 workgroups -- fewer partials to add, and the arithmetic
-    // no longer wants more CUs.  LCREC_SINKHORN_SCALING=0: the in-place form below.
-    static const bool allow_scaling = [] { const char *e = getenv("LCREC_SINKHORN_SCALING"); return !e || atoi(e) != 0; }();
-    static const int nblk_target = [] { const char *e = getenv("LCREC_SK_BLOCKS"); return e ? atoi(e) : 16; }();
-    if (allow_scaling && K % 64 == 0 && K <= 1024) {
-        const int cpl_s = K / 64, cpl_t = cpl_s <= 1 ? 1 : cpl_s <= 2 ? 2 : cpl_s <= 4 ? 4 : cpl_s <= 8 ? 8 : 16;
-        const int rw_cap = cpl_t == 1 ? 8 : cpl_t <= 4 ? 16 : (cpl_t <= 8 ? 8 : 4);   // (<1, 16> spills: not instantiated)
-        int rw = 2;
-        while (rw < rw_cap && (B + 8 * rw - 1) / (8 * rw) > nblk_target) rw *= 2;
-        const int64_t nblk_s = (B + 8 * rw - 1) / (8 * rw);
-        if (nblk_s <= 64 && 3 * nblk_s <= B) {                   // the exchange buffers live in the unused Q region ([B][K] doubles)
-            SkScale q;
-            q.d = d; q.part = p.Q; q.minmax = minmax; q.flag = minmax + 5;
-            q.B = B; q.K = K; q.nblk = (int)nblk_s; q.iters = iters; q.eps = eps;
-            q.idx_out = idx_out; q.idx_stride = idx_stride;
-            bool launched;
-            if (cpl_t == 1) launched = launch_sks_rw<1>(q, rw, stream);
-            else if (cpl_t == 2) launched = launch_sks_rw<2>(q, rw, stream);
-            else if (cpl_t == 4) launched = launch_sks_rw<4>(q, rw, stream);
-            else if (cpl_t == 8) launched = launch_sks_rw<8>(q, rw, stream);
-            else launched = launch_sks_rw<16>(q, rw, stream);
-            if (launched) return check_launch("sk_scaling_kernel");
-        }
+    if (scaling) {
+        SkScale q;
+        q.d = d; q.part = p.Q; q.minmax = minmax; q.flag = minmax + 5;
+        q.B = B; q.K = K; q.nblk = (int)nblk_s; q.iters = iters; q.eps = eps;
+        q.idx_out = idx_out; q.idx_stride = idx_stride;
+        bool launched;
+        if (cpl_t == 1) launched = launch_sks_rw<1>(q, rw, stream);
+        else if (cpl_t == 2) launched = launch_sks_rw<2>(q, rw, stream);
+        else if (cpl_t == 4) launched = launch_sks_rw<4>(q, rw, stream);
+        else if (cpl_t == 8) launched = launch_sks_rw<8>(q, rw, stream);
+        else launched = launch_sks_rw<16>(q, rw, stream);
+        if (launched) return check_launch("sk_scaling_kernel");
     }
     // one-launch register-resident path when every workgroup can be resident (see sk_persistent_kernel)
     const int cpl = (K + 63) / 64;
