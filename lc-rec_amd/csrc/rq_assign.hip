@@ -50,6 +50,7 @@ struct RqParams {
     float *margin;         // [n][L]: second smallest distance minus the smallest, per level; or NULL
     uint32_t *neartie;     // [n]: bit l set when margin_l <= tie_tau * (xx_l + cc_l[idx_l]); or NULL
     float tie_tau;
+    int split;             // batch-sized inputs: one 64-item tile per WORKGROUP, a level's code blocks dealt over its waves
 };
 
 __device__ __forceinline__ void swap32(float a, float b, float &lo_pair, float &hi_pair)
@@ -75,6 +76,8 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
     float *cbs = smem;                       // [rows][S]
     float *ccs = smem + (size_t)p.rows * S;  // [rows]
     double *wave_sse = reinterpret_cast<double *>(ccs + ((p.rows + 3) & ~3));  // [WAVES][L]
+    // (split) per-level hand-over of the waves' partial argmins: [2 parities][WAVES][64 lanes] x {distance, index, second}
+    float *ex = reinterpret_cast<float *>(wave_sse + (size_t)WAVES * p.L);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
@@ -117,8 +120,17 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             ccs[row] = __builtin_inff();
     __syncthreads();
 
+    // Split form (batch-sized inputs, a training step's 1-4 k rows): with one tile per wave a 1024-row batch is 16 waves
+    // on 16 SIMDs, each walking all of a level's code blocks (8 x 32 MFMAs at 256 codes) level after level -- 43 us of a
+    // 1.2 ms step.  Here every wave of a workgroup holds the SAME 64 items and takes a contiguous share of the level's code
+    // blocks; the partial (best, index, second) of each wave meet in LDS and every wave applies the same winner, so the
+    // residuals stay identical in all of them.  Ties still go to the lowest code (lower waves hold lower codes).  Only wave 0
+    // writes results and accumulates the sums of squares.
+    const bool split = p.split != 0;
+    const bool writer = !split || wave == 0;
     const int64_t tiles = (p.n + 63) / 64;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES + wave, GW = (int64_t)gridDim.x * WAVES;
+    const int64_t gw = split ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t GW = split ? (int64_t)gridDim.x : (int64_t)gridDim.x * WAVES;
 
     for (int64_t tile = gw; tile < tiles; tile += GW) {
         const int64_t item = tile * 64 + lane;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             const int ro = p.row_off[l];
             const int nblk = (p.K[l] + 31) >> 5;
 
-            if (p.resid_levels && valid) {
+            if (p.resid_levels && valid && writer) {
                 f32x4 *dst = reinterpret_cast<f32x4 *>(p.resid_levels + ((size_t)l * p.n + item) * E);
 #pragma unroll
                 for (int q = 0; q < E / 4; ++q) {
@@ -181,7 +193,9 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             float sec0 = __builtin_inff(), sec1 = __builtin_inff();
             int bi0 = 0, bi1 = 0;
 
-            for (int b = 0; b < nblk; ++b) {
+            const int per = split ? (nblk + WAVES - 1) / WAVES : nblk;
+            const int b_lo = split ? wave * per : 0, b_hi = b_lo + per < nblk ? b_lo + per : nblk;
+            for (int b = b_lo; b < b_hi; ++b) {
                 const float *arow = cbs + (ro + b * 32 + c) * S + h * H;
                 float af[H];
 #pragma unroll
@@ -230,17 +244,39 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             swap32(__int_as_float(bi0), __int_as_float(bi1), fA, fB);
             const int iA = __float_as_int(fA), iB = __float_as_int(fB);
             const bool takeB = (dB < dA) || (dB == dA && iB < iA);
-            const int bi = takeB ? iB : iA;
-
-            if (valid) p.idx_out[item * p.L + l] = (int64_t)bi;
+            int bi = takeB ? iB : iA;
+            float win = takeB ? dB : dA, second = __builtin_inff();
             if (WANT_MARGIN) {
                 float sA, sB;
                 swap32(sec0, sec1, sA, sB);
                 const float lose = takeB ? dA : dB, wsec = takeB ? sB : sA;     // the loser's best, the winner's second
-                const float win = takeB ? dB : dA;
-                const float second = lose < wsec ? lose : wsec;
+                second = lose < wsec ? lose : wsec;
+            }
+            if (split) {
+                // this wave's (best, index, second) over ITS code blocks -> LDS; then every wave merges all of them in wave
+                // order.  Parity buffers: a wave may be a level ahead of another, never two (the barrier below).
+                float *mine = ex + ((size_t)((l & 1) * WAVES + wave) * 64 + lane) * 3;
+                mine[0] = win; mine[1] = __int_as_float(bi); mine[2] = second;
+                __syncthreads();
+                const float *all = ex + ((size_t)(l & 1) * WAVES * 64 + lane) * 3;
+                win = all[0]; bi = __float_as_int(all[1]); second = all[2];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) {
+                    const float dw = all[(size_t)w * 64 * 3], sw = all[(size_t)w * 64 * 3 + 2];
+                    const int iw = __float_as_int(all[(size_t)w * 64 * 3 + 1]);
+                    if (dw < win || (dw == win && iw < bi)) {            // the new winner's second, or the old winner
+                        second = win < sw ? win : sw;
+                        win = dw; bi = iw;
+                    } else {
+                        second = dw < second ? dw : second;
+                    }
+                }
+            }
+
+            if (valid && writer) p.idx_out[item * p.L + l] = (int64_t)bi;
+            if (WANT_MARGIN) {
                 const float margin = second - win;
-                if (p.margin && valid) p.margin[item * p.L + l] = margin;
+                if (p.margin && valid && writer) p.margin[item * p.L + l] = margin;
                 const float scale = xx + ccs[ro + bi];
                 if (margin <= p.tie_tau * scale) tie_bits |= 1u << l;
             }
@@ -267,7 +303,7 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
                 if (WANT_XQ) xq[k] = xq[k] + s;
                 r[k] = r[k] - s;
             }
-            if (p.sse_partial) {
+            if (p.sse_partial && writer) {
                 double v = valid ? (double)sse : 0.0;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -275,8 +311,8 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             }
         }
 
-        if (WANT_MARGIN && p.neartie && valid) p.neartie[item] = tie_bits;
-        if (valid) {
+        if (WANT_MARGIN && p.neartie && valid && writer) p.neartie[item] = tie_bits;
+        if (valid && writer) {
             if (WANT_XQ) {
                 f32x4 *dst = reinterpret_cast<f32x4 *>(p.xq + item * E);
 #pragma unroll
@@ -329,9 +365,10 @@ __global__ void rq_sse_finalize_kernel(const double *partial, int blocks, int L,
 constexpr size_t LDS_BUDGET = 160 * 1024;
 constexpr int MAX_GRID = 256;   // one persistent workgroup per CU
 
-static size_t lds_bytes(int rows, int E, int L, int waves)
+static size_t lds_bytes(int rows, int E, int L, int waves, bool split = false)
 {
-    return ((size_t)rows * (E + 4) + ((rows + 3) & ~3)) * sizeof(float) + (size_t)waves * L * sizeof(double);
+    return ((size_t)rows * (E + 4) + ((rows + 3) & ~3)) * sizeof(float) + (size_t)waves * L * sizeof(double) +
+           (split ? (size_t)2 * waves * 64 * 3 * sizeof(float) : 0);      // the split form's hand-over buffers
 }
 
 static int threads_for(int e, int64_t n)
@@ -402,11 +439,16 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e_dim=%d (supported: 16, 32, 64)", e);
     if (((uintptr_t)z | (uintptr_t)codebooks | (uintptr_t)xq_out | (uintptr_t)resid_out) & 15)
         return fail(LCREC_EINVAL, "rq_assign: buffers must be 16-byte aligned");
-    const int threads = threads_for(e, n);
+    // batch-sized inputs (at most 64 tiles of 64 items) with enough code blocks to deal out: the split form (see the kernel)
+    int max_k = 0;
+    for (int l = 0; l < L; ++l) max_k = K[l] > max_k ? K[l] : max_k;
+    static const bool allow_split = [] { const char *v = getenv("LCREC_RQ_SPLIT"); return !v || atoi(v) != 0; }();
+    const bool split = allow_split && n > 0 && (n + 63) / 64 <= 64 && max_k >= 128;
+    const int threads = split ? 256 : threads_for(e, n);
     const int waves = threads / 64;
     for (int l = 0; l < L; ++l) {
         if (K[l] <= 0) return fail(LCREC_EINVAL, "rq_assign: K[%d]=%d", l, K[l]);
-        if (lds_bytes((K[l] + 31) & ~31, e, L, waves) > LDS_BUDGET)
+        if (lds_bytes((K[l] + 31) & ~31, e, L, waves, split) > LDS_BUDGET)
             return fail(LCREC_EUNSUPPORTED, "rq_assign: level %d (K=%d, e=%d) does not fit in 160 KB of LDS", l, K[l], e);
     }
     if (n == 0) return LCREC_OK;
@@ -417,7 +459,7 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     float *ping = reinterpret_cast<float *>(workspace);
     float *pong = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + resid_bytes);
     double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 2 * resid_bytes);
-    const int grid = grid_for(n, threads);
+    const int grid = split ? (int)((n + 63) / 64) : grid_for(n, threads);
 
     // Greedily pack consecutive levels into launches whose codebooks fit in LDS.
     int64_t cb_offs[LCREC_MAX_LEVELS];
@@ -430,7 +472,7 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     while (l0 < L) {
         RqParams p = {};
         int rows = 0, l1 = l0;
-        while (l1 < L && lds_bytes(rows + ((K[l1] + 31) & ~31), e, L, waves) <= LDS_BUDGET) {
+        while (l1 < L && lds_bytes(rows + ((K[l1] + 31) & ~31), e, L, waves, split) <= LDS_BUDGET) {
             p.row_off[l1] = rows;
             rows += (K[l1] + 31) & ~31;
             ++l1;
@@ -447,10 +489,11 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
         p.margin = margin_out;
         p.neartie = neartie_out;
         p.tie_tau = tie_tau;
+        p.split = split ? 1 : 0;
         float *next = nullptr;
         if (l1 < L) next = (zin == ping) ? pong : ping;
         p.resid_next = next;
-        const size_t lds = lds_bytes(rows, e, L, waves);
+        const size_t lds = lds_bytes(rows, e, L, waves, split);
         int rc;
         if (e == 16) rc = dispatch<16>(p, threads, grid, lds, xq_out != nullptr, stream);
         else if (e == 32) rc = dispatch<32>(p, threads, grid, lds, xq_out != nullptr, stream);

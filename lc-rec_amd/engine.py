@@ -319,9 +319,16 @@ class TrainEngine:
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
+        # Data parallel: the process group's watchdog THREAD polls the events of collectives issued before the capture
+        # (hipEventQuery); in the default "global" capture mode such a call from any thread is an error that invalidates the
+        # capture -- and kills the watchdog, which takes the process down (seen once in ~10 runs).  "thread_local" confines the
+        # check to this thread, whose own calls are all capturable.
+        mode = "thread_local" if self.dist is not None else "global"
+        if self.dist is not None:
+            torch.cuda.synchronize(self.device)          # (and nothing of the eager steps' collectives is left for it to poll)
         try:
             with torch.no_grad(), ops.deferred_checks():
-                with torch.cuda.graph(graph, stream=side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
                     self._run(static, eager=False)
         except RuntimeError as err:
             if self.dist is None:
