@@ -443,7 +443,9 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     int max_k = 0;
     for (int l = 0; l < L; ++l) max_k = K[l] > max_k ? K[l] : max_k;
     static const bool allow_split = [] { const char *v = getenv("LCREC_RQ_SPLIT"); return !v || atoi(v) != 0; }();
-    const bool split = allow_split && n > 0 && (n + 63) / 64 <= 64 && max_k >= 128;
+    bool split = allow_split && n > 0 && (n + 63) / 64 <= 64 && max_k >= 128;
+    for (int l = 0; split && l < L; ++l)       // (its hand-over buffers must not push a level out of LDS that fits without them)
+        if (K[l] > 0 && lds_bytes((K[l] + 31) & ~31, e, L, 4, true) > LDS_BUDGET) split = false;
     const int threads = split ? 256 : threads_for(e, n);
     const int waves = threads / 64;
     for (int l = 0; l < L; ++l) {
