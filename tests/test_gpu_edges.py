@@ -33,7 +33,9 @@ def test_empty_batches_are_a_no_op(hip):
 
 def test_single_rows_and_maximum_depth(hip, oracle):
     rs = np.random.RandomState(1)
-    for n, e, Ks in ((1, 64, [512]), (3, 16, [32] * 16), (65, 32, [1024, 32, 1, 7])):
+    # (the last case: a codebook that fits in LDS only without the split form's hand-over buffers -- small batches then take
+    # the one-tile-per-wave form)
+    for n, e, Ks in ((1, 64, [512]), (3, 16, [32] * 16), (65, 32, [1024, 32, 1, 7]), (100, 32, [1088, 256])):
         z = rs.standard_normal((n, e)).astype(np.float32)
         cbs = [rs.standard_normal((K, e)).astype(np.float32) for K in Ks]
         want = oracle.rq_assign(z, cbs)
