@@ -97,14 +97,14 @@ class DeviceLoader:
             order = None
         for lo in range(0, n, self.batch_size):
             hi = min(n, lo + self.batch_size)
+            self.last_global_rows = hi - lo
+            if self.world_size > 1:
+                # item-sharded data parallel: every rank walks the same global batches and gathers only its own slice of each
+                from .dist import batch_slice
+                a, b = batch_slice(hi - lo, self.rank, self.world_size)
+                lo, hi = lo + a, lo + b
             if order is None:
                 batch = self.data[lo:hi]
             else:
                 batch = self.data.index_select(0, order[lo:hi])
-            self.last_global_rows = hi - lo
-            if self.world_size > 1:
-                # item-sharded data parallel: every rank walks the same global batch and keeps its slice
-                from .dist import batch_slice
-                a, b = batch_slice(batch.shape[0], self.rank, self.world_size)
-                batch = batch[a:b]
             yield batch
