@@ -158,6 +158,52 @@ def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=12.0):
                       f"oracle/torch_ref.get_indices (torch CPU ops of rqvae.py:68-72)"}
 
 
+def secondary_metrics(dev, cbs, ks):
+    """SURVEY.md section 8d's secondary figures, measured after the timed region on rank 0 at N=1 (never part of `value`):
+    quantizer-only throughput ([n, 32] latents resident in HBM -> indices, lcrec_rq_assign alone) and the training step of
+    the shipped recipe (index/run.sh: batch 1024, 4 x 256 codes, Sinkhorn on the last level, BatchNorm on) as
+    lcrec_amd.engine runs it -- one captured hipGraph per step, synthetic 768-d batch, random-init weights."""
+    import lcrec_amd
+    from lcrec_amd import ops
+    from lcrec_amd.engine import TrainEngine
+    out = {}
+    n = 1_000_000
+    z = torch.randn((n, cbs[0].shape[1]), device=dev)
+    flat, kk = ops.flatten_codebooks(cbs)
+    for _ in range(2):
+        ops.rq_assign(z, flat, kk)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.rq_assign(z, flat, kk)
+    e1.record()
+    torch.cuda.synchronize()
+    out["quantizer_only_items_per_s"] = n * 10 / (e0.elapsed_time(e1) * 1e-3)
+    del z
+    torch.manual_seed(2024)
+    model = lcrec_amd.RQVAE(in_dim=768, num_emb_list=[256] * 4, e_dim=32, layers=HIDDEN, bn=True, kmeans_init=False,
+                            sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50).to(dev)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    eng = TrainEngine(model, opt, "linear", 10, 10_000)
+    batch = torch.randn((1024, 768), device=dev)
+    for _ in range(5):
+        eng.step(batch)
+    torch.cuda.synchronize()
+    steps = 50
+    e0.record()
+    for _ in range(steps):
+        eng.step(batch)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    eng.end_epoch(None)                                        # raises if a step's loss was NaN or a solver gave up
+    out["train_step_ms"] = ms
+    out["train_items_per_s"] = 1024 / (ms * 1e-3)
+    out["train_config"] = "batch 1024 x 768-d, 4 x 256 codes, Sinkhorn on the last level, bn=True, AdamW + clip + linear warm-up; one hipGraph per step"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +212,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--items", type=int, default=0, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the quantizer-only and training-step figures (N=1 only)")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="chunk pipelines of lcrec_encode_assign (lcrec_context_set_pipelines); 0 = the library's default (1)")
     ap.add_argument("--rehearse-rccl", action="store_true",
@@ -383,6 +430,11 @@ def main():
             if not args.no_cpu_baseline:
                 sample = x[: min(n, 200_000)].cpu()
                 out["cpu_baseline"] = cpu_baseline(sample, dims, Ws, bs, cbs)
+            if not args.no_secondary:
+                try:
+                    out["secondary"] = secondary_metrics(device, cbs, ks)
+                except Exception as err:                       # never at the expense of the line itself
+                    out["secondary"] = {"error": f"{type(err).__name__}: {err}"}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

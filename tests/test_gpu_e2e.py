@@ -174,3 +174,5 @@ def test_bench_line_and_its_collective_path_over_a_one_rank_rccl_group(hip):
     r = line["roofline"]
     assert r["bound"] == "mfma" and 0.3 < r["frac"] < 1.0 and r["kernel"] == "linear_fwd_pp_256x128"
     assert line["parity_mismatch_rows"] == 0 and 0 <= line["neartie_rows"] < 0.01 * 150000
+    sec = line["secondary"]             # SURVEY.md section 8d's secondary figures ride along, outside the timed region
+    assert "error" not in sec and sec["quantizer_only_items_per_s"] > 1e8 and 0.3 < sec["train_step_ms"] < 20.0
