@@ -501,6 +501,88 @@ def fixture_trainer(manifest):
                 "(transformers), main.py:14-49 CLI defaults and the type=bool quirk"}
 
 
+# --------------------------------------------------------------------------- F11
+def fixture_run_sh_step(ref, manifest):
+    """One trainer.py:111-120 step of the model index/run.sh actually trains -- 768 -> 2048-1024-512-256-128-64 -> 32 with
+    BatchNorm (layers.py:19-30), 4 x 256 codes, Sinkhorn (eps 0.003) on the last level, batch 1024 -- through the imported
+    reference in fp32 AND in fp64 (model.double()).  fp64 is the yardstick: |fp32 - fp64| of the reference itself is how far
+    ANY fp32 evaluation of this step may sit from the true gradient, tensor by tensor (the last encoder BatchNorm's backward
+    cancels ~5 digits).  Stored per precision: losses, gradient norm, per-tensor gradient L2 norms, a strided sample of
+    every gradient tensor."""
+    import copy
+    sd_np, x_np = gi.run_sh_train_case()
+    kw = dict(in_dim=768, num_emb_list=[256] * 4, e_dim=32, layers=gi.RUN_SH_LAYERS, dropout_prob=0.0, bn=True,
+              loss_type="mse", quant_loss_weight=1.0, beta=0.25, kmeans_init=False, kmeans_iters=100,
+              sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+    model = ref["rqvae"].RQVAE(**kw)
+    sd = model.state_dict()
+    for k, v in sd_np.items():
+        assert k in sd and tuple(sd[k].shape) == tuple(np.shape(v)), k
+        sd[k] = t(np.asarray(v))
+    model.load_state_dict(sd)
+    x = t(x_np)
+    # data-scale codebooks: rows of each level's residual of the training-mode latents + a little noise (the stand-in for
+    # k-means, which is sklearn and unpinned); stored, since the latents come through MKL
+    model.train()
+    with torch.no_grad():
+        resid = model.encoder(x)
+        g = torch.Generator().manual_seed(11)
+        cbs = []
+        for l in range(4):
+            cb = resid[torch.randperm(1024, generator=g)[:256]] + 0.01 * resid.std() * torch.randn(256, 32, generator=g)
+            cbs.append(cb.clone())
+            model.rq.vq_layers[l].embedding.weight.data.copy_(cb)
+            resid = resid - cb[torch.argmin(torch_ref.distances(resid, cb), -1)]
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.reset_running_stats()
+    arrays = {"codebooks": torch.stack(cbs).numpy()}
+    runs = {}
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        mm = copy.deepcopy(model).to(dtype)
+        mm.train()
+        opt = torch.optim.AdamW(mm.parameters(), lr=1e-3, weight_decay=1e-4)
+        opt.zero_grad()
+        out, rq_loss, idx = mm(x.to(dtype))
+        loss, recon = mm.compute_loss(out, rq_loss, xs=x.to(dtype))
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in mm.named_parameters()}
+        gn = torch.nn.utils.clip_grad_norm_(mm.parameters(), 1.0)
+        runs[tag] = dict(idx=idx.numpy(), loss=float(loss), recon=float(recon), rq_loss=float(rq_loss), grad_norm=float(gn),
+                         grads=grads, latent=None)
+        arrays[f"{tag}__scalars"] = np.asarray([float(loss), float(recon), float(rq_loss), float(gn)], dtype=np.float64)
+        for k, gk in grads.items():
+            arrays[f"{tag}__norm__{k}"] = np.float64(gk.double().norm().item())
+            arrays[f"{tag}__sample__{k}"] = gi.strided_sample(gk.numpy())
+    arrays["idx"] = runs["f32"]["idx"].astype(np.int16)
+    flips = int((runs["f32"]["idx"] != runs["f64"]["idx"]).any(1).sum())
+    arrays["idx_f64"] = runs["f64"]["idx"].astype(np.int16)
+    # the oracle's torch restatement, fp32, must be the reference bit for bit (same machine)
+    spec = torch_ref.Spec(768, [256] * 4, 32, gi.RUN_SH_LAYERS, bn=True, sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+            for k, v in model.state_dict().items()}
+    o2, r2, i2 = torch_ref.forward(spec, leaf, x, use_sk=True, training=True)
+    l2, _ = torch_ref.compute_loss(spec, o2, r2, x)
+    l2.backward()
+    same = float(l2) == runs["f32"]["loss"] and all(torch.equal(leaf[k].grad, gk) for k, gk in runs["f32"]["grads"].items())
+    rel = {}
+    for k in runs["f32"]["grads"]:
+        a, b = runs["f32"]["grads"][k].double(), runs["f64"]["grads"][k]
+        rel[k] = float((a - b).norm() / b.norm())
+    name = save("f11_run_sh_step.npz", **arrays)
+    manifest["fixtures"][name] = {
+        "pins": "trainer.py:111-120 one step (forward, compute_loss, backward, clip_grad_norm_) at index/run.sh's architecture, "
+                "bn=True (layers.py:19-30), batch 1024, in fp32 and fp64",
+        "inputs": "golden_inputs.run_sh_train_case(); codebooks stored",
+        "model": kw, "torch_ref_bit_identical": bool(same), "rows_assigned_differently_in_fp64": flips,
+        "scalars_f32": arrays["f32__scalars"].tolist(), "scalars_f64": arrays["f64__scalars"].tolist(),
+        "reference_f32_vs_f64_gradient_rel_err": rel}
+    print("  F11 reference fp32 vs fp64, relative gradient error per tensor:")
+    for k, v in rel.items():
+        print(f"    {k:40s} {v:.3e}")
+    print(f"  F11 rows assigned differently in fp64: {flips}; torch_ref bit-identical: {same}")
+
+
 # --------------------------------------------------------------------------- F10
 def fixture_kmeans(ref, manifest):
     """The reference's kmeans() (index/models/layers.py:69-82: sklearn KMeans(n_clusters, max_iter).fit on the host,
@@ -545,6 +627,9 @@ def main():
         if want is None or name in want:
             print("generating", name, flush=True)
             fn()
+    if want is None or "run_sh_step" in want:
+        print("generating run_sh_step", flush=True)
+        fixture_run_sh_step(ref, manifest)
     if want is None or "kmeans" in want:
         print("generating kmeans", flush=True)
         fixture_kmeans(ref, manifest)

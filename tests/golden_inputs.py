@@ -140,3 +140,31 @@ def kmeans_case(seed=1000, n=2048, e=32, centres=300):
     r = rs(seed)
     c = f32(r.standard_normal((centres, e)))
     return f32(c[r.randint(0, centres, size=n)] + 0.15 * r.standard_normal((n, e)))
+
+
+# ---------------------------------------------------------------- F11: one training step at the run.sh width
+def run_sh_train_case(in_dim=768, batch=1024, e=32, seed=1100):
+    """The model index/run.sh trains (MLP 2048-...-64, e 32, BatchNorm -- run.sh's `--bn False` parses as True) with
+    Xavier-normal-scaled weights from numpy, BatchNorm affine parameters off 1/0, fresh running statistics, and one
+    batch of run.sh's size.  Returns (state dict without codebooks: name -> array, x [batch, in_dim])."""
+    dims = [in_dim] + RUN_SH_LAYERS + [e]
+    names = state_dict_names(len(dims) - 1, True, 4)
+    sd = {}
+    for part, d, s in (("encoder", dims, seed), ("decoder", dims[::-1], seed + 7)):
+        Ws, bs, bns = encoder_weights(d, s, bn=True)
+        for l, nme in enumerate(names[part]):
+            sd[nme + ".weight"], sd[nme + ".bias"] = Ws[l], bs[l]
+        for l, nme in enumerate(names["bn"][part]):
+            f = d[l + 1]
+            sd[nme + ".weight"], sd[nme + ".bias"] = bns[l]["weight"], bns[l]["bias"]
+            sd[nme + ".running_mean"], sd[nme + ".running_var"] = np.zeros(f, np.float32), np.ones(f, np.float32)
+            sd[nme + ".num_batches_tracked"] = np.zeros((), np.int64)
+    x = f32(rs(seed + 1).standard_normal((batch, in_dim)))
+    return sd, x
+
+
+def strided_sample(a, limit=2048):
+    """The entries of `a` (flattened) a fixture keeps: all of a small tensor, every stride-th of a large one."""
+    flat = np.asarray(a).reshape(-1)
+    step = max(1, -(-flat.size // limit))
+    return flat[::step]

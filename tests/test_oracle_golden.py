@@ -165,3 +165,35 @@ def test_neartie_fixture_c2_is_what_the_oracle_computes(oracle):
     assert sha == str(f["sha_oracle"]) == str(f["sha_ref4096"]) == str(f["sha_ref64"])
     flagged = (o["margin"] <= np.float32(f["tau"]) * o["scale"]).any(1)
     assert int(flagged.sum()) == int(f["flagged_count"]) and len(f["rows"]) == 0
+
+
+def test_torch_ref_training_step_at_the_run_sh_width_against_fp64_reference():
+    """F11: one trainer.py:111-120 step of the run.sh model (BatchNorm, Sinkhorn level, batch 1024) through the oracle's
+    torch restatement in fp32, judged against the reference's fp64 gradients with the reference's own fp32 run as the
+    measure of what fp32 can deliver (tests/f11_check.py)."""
+    import f11_check
+    from oracle import torch_ref
+    g = gold("f11_run_sh_step.npz")
+    sd_np, x = gi.run_sh_train_case()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
+    for l in range(4):
+        sd[f"rq.vq_layers.{l}.embedding.weight"] = torch.from_numpy(g["codebooks"][l].copy())
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+            for k, v in sd.items()}
+    spec = torch_ref.Spec(768, [256] * 4, 32, gi.RUN_SH_LAYERS, bn=True, sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+    xt = torch.from_numpy(x)
+    out, rq_loss, idx = torch_ref.forward(spec, leaf, xt, use_sk=True, training=True)
+    loss, recon = torch_ref.compute_loss(spec, out, rq_loss, xt)
+    loss.backward()
+    assert np.array_equal(idx.numpy(), g["idx"].astype(np.int64))
+    assert np.array_equal(g["idx"], g["idx_f64"])                # fp64 assigns the same codes: the gradients are comparable
+    want = g["f64__scalars"]
+    np.testing.assert_allclose([loss.item(), recon.item(), rq_loss.item()], want[:3], rtol=1e-5)
+    grads = {k: v.grad.numpy() for k, v in leaf.items() if v.requires_grad}
+    rows, bad = f11_check.report(g, grads)
+    assert not bad, f11_check.table(bad)
+    norm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in grads.values()))
+    np.testing.assert_allclose(norm, want[3], rtol=1e-4)
+    # what the fixture says about fp32 itself: the first encoder layers lose 3-4 digits, the rest sits at ~1e-6
+    m = manifest()["fixtures"]["f11_run_sh_step.npz"]["reference_f32_vs_f64_gradient_rel_err"]
+    assert m["encoder.mlp_layers.1.weight"] > 1e-4 and m["decoder.mlp_layers.25.weight"] < 1e-5

@@ -79,6 +79,66 @@ def pmc(a):
         json.dump(doc, open(a.out, "w"), indent=1, sort_keys=True)
 
 
+MFMA_KERNELS = [("linear_fwd_pp3_kernel", "linear_fwd_pp3 (256x128 ping-pong)"), ("rq_assign_kernel", "rq_assign"),
+                ("linear_fwd_kernel<2, 2, 1, 1", "linear_fwd 64x64 (training step)")]
+CUS, SIMDS = 256, 4
+
+
+def mfma(dbs):
+    """Per-launch averages of the SQ counters of tools/pmc_mfma.sh for the three MFMA kernels, beside the launch duration of
+    the same (profiled) runs.  SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMD pipes; `util` divides it by
+    1024 x the launch's cycles -- taken from GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs) -- so 1.0 = every
+    MFMA pipe busy every cycle of the launch."""
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for db in dbs:
+        c = sqlite3.connect(db)
+        for name, cname, value in c.execute("select kernel_name, counter_name, value from counters_collection"):
+            for key, label in MFMA_KERNELS:
+                if key in name:
+                    vals[label][cname].append(float(value))
+        for name, d in c.execute("select name, end - start from kernels"):
+            for key, label in MFMA_KERNELS:
+                if key in name:
+                    dur[label].append(float(d))
+    for _key, label in MFMA_KERNELS:
+        if label not in vals:
+            continue
+        v = vals[label]
+        # the large launches of the target only (set-up launches and the 1-tile probes fall below half of the largest)
+        avg = {}
+        for cname, xs in v.items():
+            cut = 0.5 * max(xs)
+            keep = [x for x in xs if x >= cut] or xs
+            avg[cname] = sum(keep) / len(keep)
+        ds = dur[label]
+        dcut = 0.5 * max(ds)
+        dk = [x for x in ds if x >= dcut]
+        d_ns = sum(dk) / len(dk)
+        print(f"{label}: {len(dk)} launches per pass-set, average duration {d_ns / 1e3:.1f} us (profiled runs)")
+        for cname in sorted(avg):
+            print(f"    {cname:32s} {avg[cname]:16.0f} per launch")
+        busy, gui = avg.get("SQ_VALU_MFMA_BUSY_CYCLES"), avg.get("GRBM_GUI_ACTIVE")
+        if busy and gui:
+            cycles = gui / 8.0
+            print(f"    launch cycles (GRBM_GUI_ACTIVE / 8 XCDs) {cycles:12.0f}  -> clock {cycles / d_ns:.2f} GHz")
+            print(f"    MFMA pipe utilisation = MFMA_BUSY / ({CUS * SIMDS} pipes x cycles) = {busy / (CUS * SIMDS * cycles):.3f}")
+        if busy:
+            # GRBM_GUI_ACTIVE reads high on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back): the same
+            # ratio against the launch's wall time at the 2.4 GHz peak clock (the clock the 157.3 TFLOP/s roof assumes)
+            print(f"    MFMA_BUSY / (1024 pipes x duration x 2.4 GHz) = {busy / (CUS * SIMDS * d_ns * 2.4):.3f}")
+        n_mfma = avg.get("SQ_INSTS_MFMA")
+        if n_mfma and busy:
+            # v_mfma_f32_32x32x2_f32: 32*32*2 multiply-adds = 4096 flop, 64 pipe cycles each (busy / instructions confirms it)
+            print(f"    MFMA instructions {n_mfma:.0f} x 4096 flop / duration = {n_mfma * 4096 / d_ns / 1e3:.1f} TFLOP/s "
+                  f"(roof 157.3); busy cycles per instruction {busy / n_mfma:.1f}")
+        wc = avg.get("SQ_WAVE_CYCLES")
+        if wc:
+            for cname in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+                if cname in avg:
+                    print(f"    {cname} / SQ_WAVE_CYCLES = {avg[cname] / wc:.3f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -89,8 +149,12 @@ def main():
     p.add_argument("--write", required=True)
     p.add_argument("--workload", default="c3")
     p.add_argument("--out", default=None)
+    m = sub.add_parser("mfma")
+    m.add_argument("dbs", nargs="+")
     a = ap.parse_args()
-    if a.cmd == "stats":
+    if a.cmd == "mfma":
+        mfma(a.dbs)
+    elif a.cmd == "stats":
         stats(a.db)
     else:
         pmc(a)
