@@ -85,6 +85,7 @@ class TrainEngine:
         self._graphs = {}                                                    # batch rows -> (graph, static input)
         self._seen = {}                                                      # batch rows -> eager steps done at that size
         self.graph_replays = 0
+        self.last_idx = None
 
     # ------------------------------------------------------------------ support matrix
     @staticmethod
@@ -222,6 +223,7 @@ class TrainEngine:
             m.rq._lazy_kmeans(z.reshape(-1, m.e_dim), True)                 # vq.py:67-68, first training batch only
         cbs = [q.embedding.weight.data for q in levels]
         q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), False, True, want_loss=False)
+        self.last_idx = q["idx"]                                             # [rows, L] of the last step (a graph's static output)
         out, dec = self._mlp_forward(m.decoder, q["xq"])
         counters = [s[2].num_batches_tracked for s in enc + dec if s[2] is not None]
         if counters:

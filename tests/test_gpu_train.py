@@ -295,13 +295,12 @@ def test_engine_equals_autograd_path_on_the_run_sh_architecture(hip, bn):
         np.testing.assert_allclose(lb, la, rtol=1e-5 if i == 0 else 3e-4, err_msg=f"step {i}")
     sa, sb = a.state_dict(), b.state_dict()
     # Adam divides by sqrt(v): where a gradient entry is itself rounding noise (dead units) the update direction is too,
-    # so a small fraction of entries may sit a fraction of one step (lr = 1e-3) apart; everything else agrees closely
+    # so a small fraction of entries may sit a fraction of one step (lr = 1e-3) apart; everything else agrees closely.
+    # With BatchNorm the first encoder layers' gradients survive a 3-4 digit cancellation (fixture F11 measures it on the
+    # reference itself), so after four Adam steps the two paths' parameters are only bounded here; what pins each path at
+    # this width is test_run_sh_step_gradients_against_the_fp64_reference below.
     for k in sa:
         if bn and sa[k].dtype.is_floating_point:
-            # With BatchNorm and these synthetic codebooks the gradient that reaches the encoder is what is left of
-            # g - mean(g) - xhat * mean(g * xhat) after cancelling ~5 digits (tools/engine_diag.py: inputs of the last
-            # encoder BatchNorm's backward agree to 2e-6 between the two paths, its output to 24 %; each output equals
-            # the fp64 formula on its own inputs to 1e-7).  fp32 cannot pin such a gradient in either path: bounded only.
             assert np.abs(sb[k].cpu().numpy() - sa[k].cpu().numpy()).max() < 5e-3, k
             continue
         if sa[k].dtype.is_floating_point:
@@ -312,6 +311,65 @@ def test_engine_equals_autograd_path_on_the_run_sh_architecture(hip, bn):
             assert off.sum() <= max(8, 0.2 * off.size) and np.abs(vb - va).max() < 2e-3, (k, off.sum(), np.abs(vb - va).max())
         else:
             assert torch.equal(sa[k], sb[k]), k
+
+
+def _run_sh_model(hip, g):
+    sd_np, x = gi.run_sh_train_case()
+    model = hip.RQVAE(in_dim=768, num_emb_list=[256] * 4, e_dim=32, layers=gi.RUN_SH_LAYERS, dropout_prob=0.0, bn=True,
+                      loss_type="mse", quant_loss_weight=1.0, beta=0.25, kmeans_init=False, kmeans_iters=100,
+                      sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
+    for l in range(4):
+        sd[f"rq.vq_layers.{l}.embedding.weight"] = torch.from_numpy(g["codebooks"][l].copy())
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV).train(), torch.from_numpy(x).to(DEV)
+
+
+@pytest.mark.parametrize("path", ["engine", "autograd"])
+def test_run_sh_step_gradients_against_the_fp64_reference(hip, path):
+    """F11: the step index/run.sh actually trains (768 -> 2048-...-64 -> 32, BatchNorm, 4 x 256 codes, Sinkhorn on the last
+    level, batch 1024; trainer.py:111-120, layers.py:19-30) against the imported reference run in fp64, tensor by tensor.
+    The reference's own fp32 run is the measure of what fp32 can deliver: each of our paths must sit within
+    f11_check.SLACK x that distance of the fp64 gradient (the first encoder layers lose 3-4 digits in BatchNorm's
+    backward in ANY fp32 evaluation; everything else is pinned to ~1e-6).  The engine is checked on its eager first step
+    and again on the captured-and-replayed second one (the warm-up schedule's first learning rate is 0, so both steps
+    differentiate the same parameters)."""
+    import f11_check
+    from lcrec_amd.engine import TrainEngine
+    g = np.load(os.path.join(GOLD, "f11_run_sh_step.npz"))
+    model, x = _run_sh_model(hip, g)
+    want = g["f64__scalars"]
+    names = [k for k, _ in model.named_parameters()]
+    assert sorted(names) == sorted(f11_check.tensors(g))
+
+    def judge(grads, scalars, idx, what):
+        assert np.array_equal(idx, g["idx"].astype(np.int64)), what
+        np.testing.assert_allclose(scalars[:3], want[:3], rtol=1e-5, err_msg=what)       # loss, recon, rq_loss
+        np.testing.assert_allclose(scalars[3], want[3], rtol=1e-4, err_msg=what)         # gradient norm before clipping
+        rows, bad = f11_check.report(g, grads)
+        print(f"\n[{what}]\n" + f11_check.table(rows))
+        assert not bad, what + "\n" + f11_check.table(bad)
+
+    if path == "autograd":
+        out, rq_loss, idx = model(x)
+        loss, recon = model.compute_loss(out, rq_loss, xs=x)
+        loss.backward()
+        grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        judge(grads, [loss.item(), recon.item(), rq_loss.item(), float(norm)], idx.cpu().numpy(), "autograd path")
+        return
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    eng = TrainEngine(model, opt, "linear", 2, 10)
+    before = eng.flat_p.clone()
+    for step, what in enumerate(("engine, eager step", "engine, captured step")):
+        eng.step(x)
+        coef = eng.clip[1].item()
+        grads = {k: (p.grad / coef).cpu().numpy() for k, p in model.named_parameters()}
+        loss, recon, rq_loss = eng.last.tolist()
+        judge(grads, [loss, recon, rq_loss, eng.clip[0].item()], eng.last_idx.cpu().numpy(), what)
+        if step == 0:
+            assert torch.equal(eng.flat_p, before)           # learning rate 0 on the first step: same parameters again
+    assert eng.graph_replays == 1
 
 
 def test_trainer_uses_the_engine_and_matches_the_autograd_epochs(hip, tmp_path):
