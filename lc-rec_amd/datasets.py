@@ -85,11 +85,28 @@ class DeviceLoader:
     def __len__(self):
         return (self.data.shape[0] + self.batch_size - 1) // self.batch_size
 
+    def _check_same_seed(self, seed):
+        """Data parallel: every rank must walk the same permutation (the global batches are cut from it).  The seeds come
+        from each process's global CPU generator; anything that draws from it on one rank only would silently give that
+        rank another order -- duplicated and missing items per global batch.  One tiny collective per epoch says so."""
+        import torch.distributed as tdist
+        if not tdist.is_initialized():
+            return
+        dev = self.device if tdist.get_backend() != "gloo" else "cpu"
+        # int64 seeds as two exact doubles-free halves: MAX and MIN of (hi, lo) pairs must agree
+        t = torch.tensor([seed, -seed], dtype=torch.int64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        if int(t[0]) != seed or int(t[1]) != -seed:
+            raise RuntimeError("lcrec_amd.DeviceLoader: the ranks' shuffle seeds differ (something drew from torch's global "
+                               "generator on one rank only); the epoch order would not be the single-process one")
+
     def __iter__(self):
         n = self.data.shape[0]
         if self.shuffle:
             torch.empty((), dtype=torch.int64).random_()                       # _BaseDataLoaderIter base seed
             seed = int(torch.empty((), dtype=torch.int64).random_().item())    # RandomSampler.__iter__
+            if self.world_size > 1:
+                self._check_same_seed(seed)
             g = torch.Generator()
             g.manual_seed(seed)
             order = torch.randperm(n, generator=g).to(self.device)

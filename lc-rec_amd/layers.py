@@ -34,6 +34,8 @@ class _BatchNormAct(torch.autograd.Function):
         n_local = t.shape[0]
         if world.enabled:
             mean, rstd, n_total = sharded_bn_statistics(world, t, bn)
+            if n_total < 2:                    # the GLOBAL row count, known to every rank: all of them raise here together
+                raise ValueError(f"Expected more than 1 value per channel when training, got a global batch of {n_total} row(s)")
             y = ops.bn_relu_apply(t, gamma.detach(), beta.detach(), mean, rstd, relu)
         else:
             n_total = n_local
@@ -75,9 +77,19 @@ def sharded_bn_statistics(world, t, bn):
 
 
 def _own_batchnorm(bn, x):
-    """Whether the library's BatchNorm kernels apply to this module call (else torch's own module runs)."""
-    return (type(bn) is nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
-            and x.is_cuda and x.dim() == 2 and x.shape[0] >= 2 and torch.is_grad_enabled())
+    """Whether the library's BatchNorm kernels apply to this module call (else torch's own module runs).
+    Under data parallelism the batch is the GLOBAL one: a rank may hold a single row of it (the last global batch of an
+    epoch with W .. 2W-1 rows on W ranks), and torch's own module would normalise with per-rank statistics -- or raise on
+    that rank alone while its peers wait in the statistics exchange.  There the library kernels are the only path; a
+    module they do not cover raises on every rank alike."""
+    covered = (type(bn) is nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+               and x.is_cuda and x.dim() == 2)
+    if ldist.current().enabled and bn.training:
+        if not covered:
+            raise ops._lib.LcrecError("data-parallel training: this BatchNorm configuration is not covered by the library's "
+                                      "global-batch kernels (needs BatchNorm1d, affine, running statistics, momentum, 2-d device input)")
+        return True
+    return covered and x.shape[0] >= 2 and torch.is_grad_enabled()
 
 
 class _LinearAct(torch.autograd.Function):
@@ -265,8 +277,10 @@ class MLPLayers(nn.Module):
                 bn = mods[g["bn"]]
                 if self.training:
                     x = _LinearAct.apply(x, lin.weight, lin.bias, False)
-                    if _own_batchnorm(bn, x) and (relu_mod is None or is_relu):
+                    if _own_batchnorm(bn, x):
                         x = _BatchNormAct.apply(x, bn.weight, bn.bias, bn, is_relu)     # batch statistics (+ ReLU), own kernels
+                        if relu_mod is not None and not is_relu:
+                            x = relu_mod(x)
                         continue
                     x = bn(x)                      # batch statistics + running-stat update (torch)
                     if relu_mod is not None:
@@ -291,13 +305,13 @@ class MLPLayers(nn.Module):
 KMEANS_IMPL = "sklearn"          # "sklearn" (the reference's host call) or "device"; main.py --kmeans_impl
 
 
-def kmeans(samples, num_clusters, num_iters=10):
+def kmeans(samples, num_clusters, num_iters=10, generator=None):
     """layers.py:69-82: sklearn KMeans on the host (k-means++ from numpy's global RNG), centres
     returned on the samples' device.  Runs once per level per training run; the sklearn call is the
     reference's own behaviour and its result is not bit-pinned.
-    With KMEANS_IMPL == "device" the clustering stays in HBM (kmeans_device)."""
+    With KMEANS_IMPL == "device" the clustering stays in HBM (kmeans_device; `generator` seeds its k-means++ draws)."""
     if KMEANS_IMPL == "device":
-        return kmeans_device(samples, num_clusters, num_iters)
+        return kmeans_device(samples, num_clusters, num_iters, generator=generator)
     from sklearn.cluster import KMeans
     x = samples.detach().cpu().numpy()
     cluster = KMeans(n_clusters=num_clusters, max_iter=num_iters).fit(x)

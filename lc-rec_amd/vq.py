@@ -60,8 +60,14 @@ class VectorQuantizer(nn.Module):
         if world.enabled:                      # rank 0 clusters the gathered batch, everyone gets its centres
             data = world.gather_rows(data.contiguous())
             centers = torch.zeros_like(self.embedding.weight.data)
+            # the device k-means seeds its draws from torch's global CPU generator, which the loaders' shuffles share:
+            # EVERY rank makes the draw, so the ranks' generators -- and with them the epoch orders -- stay in step
+            generator = None
+            if layers.KMEANS_IMPL == "device":
+                seed = int(torch.empty((), dtype=torch.int64).random_().item())
+                generator = torch.Generator(device=data.device).manual_seed(seed)
             if world.rank == 0:
-                centers.copy_(layers.kmeans(data, self.n_e, self.kmeans_iters))
+                centers.copy_(layers.kmeans(data, self.n_e, self.kmeans_iters, generator=generator))
             world.broadcast_(centers, src=0)
         else:
             centers = layers.kmeans(data, self.n_e, self.kmeans_iters)

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, tmp, ema, bn=False, rccl=False, engine="auto"):
+def _run(rank, world, port, tmp, ema, bn=False, rccl=False, engine="auto", rows=300):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if world > 1 or rccl:
@@ -42,7 +42,7 @@ def _run(rank, world, port, tmp, ema, bn=False, rccl=False, engine="auto"):
     cli.seed_everything(2024)
     model = cli.build_model(args, 48)
     g = torch.Generator().manual_seed(7)
-    data = torch.randn((300, 48), generator=g).to("cuda:0")          # 300 = 3 batches of 96 + a ragged one of 12
+    data = torch.randn((300, 48), generator=g)[:rows].to("cuda:0")   # 300 = 3 batches of 96 + a ragged one of 12
     loader = DeviceLoader(data, 96, True, "cuda:0", rank=ctx.rank, world_size=ctx.world_size)
     trainer = Trainer(args, model, len(loader))
     ldist.attach(trainer, ctx)
@@ -91,6 +91,19 @@ def test_two_ranks_reproduce_the_single_process_epoch(hip, tmp_path, ema, bn, en
             scale = max(1e-6, float(np.abs(a).max()))
             worst = max(worst, float(np.abs(a - b).max()) / scale)
     assert worst < 5e-3, worst        # different reduction orders, a few Sinkhorn near-ties; not bitwise
+
+
+@pytest.mark.parametrize("engine", ["auto", "off"])
+def test_two_ranks_with_a_last_global_batch_of_world_plus_one_rows(hip, tmp_path, engine):
+    """291 items at batch 96 leave a last GLOBAL batch of 3 rows = 2 + 1 on two ranks: the rank holding one row must take
+    the global-batch BatchNorm path (torch's own module would raise "Expected more than 1 value per channel" on that rank
+    alone and leave its peer waiting in the statistics exchange).  Engine and autograd path against the single process."""
+    tmp = str(tmp_path)
+    mp.spawn(_run, args=(1, 0, tmp, False, True, False, "auto", 291), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), tmp, False, True, False, engine, 291), nprocs=2, join=True)
+    one, two = np.load(os.path.join(tmp, "world1.npz")), np.load(os.path.join(tmp, "world2.npz"))
+    np.testing.assert_allclose(two["losses"], one["losses"], rtol=5e-4)
+    assert float(two["rate"]) == pytest.approx(float(one["rate"]), abs=2e-2)
 
 
 def _gen(rank, world, port, tmp):
