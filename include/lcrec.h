@@ -31,7 +31,15 @@
  *     chain over k ascending starting at 0 (v_mfma_f32_32x32x2_f32 semantics);
  *     results are bit-identical to oracle/lcrec_oracle.c.  One documented
  *     exception: the weight gradient of lcrec_linear_backward is an ordered sum
- *     of a few such chains over runs of the batch (see there).
+ *     of a few such chains over runs of the batch (see there);
+ *   - `ticket` arguments (ABI 3): a device pointer to ONE 4-byte word owned by the caller, or NULL.
+ *     The word must be zero before its first use and every call that takes it leaves it zero.
+ *     A call that sums per-workgroup partials finishes that sum in a second, one-workgroup launch;
+ *     given a ticket, the workgroups count their arrivals in it and the last one to arrive adds
+ *     the partials instead -- in the same order, so the result has the same bits -- and the second
+ *     launch disappears (a training step makes ~80 launches and a fifth of them are such tails,
+ *     4-5 us each).  Nothing waits on the word, so the dispatch order cannot deadlock a call.
+ *     Calls that share a ticket must be ordered on one stream (or one captured graph branch).
  */
 #ifndef LCREC_H
 #define LCREC_H
@@ -43,7 +51,7 @@
 extern "C" {
 #endif
 
-#define LCREC_ABI_VERSION 2
+#define LCREC_ABI_VERSION 3
 
 #define LCREC_OK 0
 #define LCREC_EINVAL (-1)      /* bad argument (shape, NULL pointer, unsupported size) */
@@ -138,7 +146,9 @@ int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, int count, v
  *                                    (= torch.cat of rq.get_codebook() rows, rq.py:32-37)
  *   K          host   [L]            codes per level (any positive count; a level must fit
  *                                    in LDS: roundup32(K)*(e+5)*4 bytes <= ~156 KB)
- *   idx_out    device [n][L] int64   (rq.py:54)
+ *   idx_out    device int64, item i's level-l code at idx_out[i*idx_stride + l] (rq.py:54);
+ *   idx_stride elements between rows, >= L; 0 = L (a dense [n][L] matrix).  A run of levels can so be
+ *                                    written straight into the columns of a wider index matrix
  *   xq_out     device [n][e] or NULL sum over levels of the straight-through x_res (rq.py:48);
  *                                    if xq_accumulate != 0 its current contents are the initial
  *                                    value of the sum (chaining a run of levels after another)
@@ -153,6 +163,7 @@ int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, int count, v
  *                                    the magnitude at which the winning distance of level l was rounded
  *   tie_tau    threshold for neartie_out (>= 0; ignored when neartie_out is NULL)
  *   workspace  device scratch of lcrec_rq_assign_workspace() bytes
+ *   ticket     NULL, or see "ticket arguments" above (finishes sse_out inside the launch)
  * e must be 16, 32 or 64.
  * Why the audit outputs exist: the reference decides vq.py:75 on fp32 distances whose summation order (MKL,
  * vectorised reductions) is unspecified and batch-size dependent (hard part 1), so an item
@@ -162,9 +173,9 @@ int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, int count, v
  * DESIGN.md section 2 states the measured rates. */
 size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-                    int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out,
+                    int64_t *idx_out, int64_t idx_stride, float *xq_out, int xq_accumulate, double *sse_out,
                     float *resid_out, float *margin_out, uint32_t *neartie_out, float tie_tau,
-                    void *workspace, size_t workspace_bytes, void *stream);
+                    void *workspace, size_t workspace_bytes, unsigned int *ticket, void *stream);
 
 /* Encoder MLP + residual quantisation: item embeddings -> index tuples.
  * Replaces RQVAE.get_indices(xs, use_sk=False), index/models/rqvae.py:68-72
@@ -215,12 +226,15 @@ int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers
  * A lone group of more than 16384/K rows is solved by one multi-workgroup launch whose workgroups must all be
  * resident: it is chosen only when the occupancy the runtime reports for its LDS size times the CU count covers
  * the grid (<= 128 workgroups), otherwise the multi-launch solver runs; every spin in it is bounded (~0.1 s in
- * total) and a timeout -- other work holding the CUs -- fills idx_out with -1 instead of hanging. */
+ * total) and a timeout -- other work holding the CUs -- fills idx_out with -1 instead of hanging.
+ * ticket (NULL, or see "ticket arguments"): the batch-sized solver's control words and exchange slots are then set up by the
+ * distance launch itself (its last workgroup reduces the global max/min of vq.py:52-53 from the workgroups' partials) instead
+ * of by a launch of their own in front of it. */
 size_t lcrec_sinkhorn_assign_workspace(int64_t n, int K, const int64_t *group_offsets, int n_groups);
 int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *codebook, int K,
                           const int64_t *group_offsets, int n_groups, double epsilon, int iters,
                           int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                          lcrec_context *ctx, void *stream);
+                          lcrec_context *ctx, unsigned int *ticket, void *stream);
 
 /* Apply a given assignment to one level: gather, squared error, straight-through estimator and
  * residual update (index/models/vq.py:87-95, index/models/rq.py:47-48) -- what follows the
@@ -228,11 +242,12 @@ int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *cod
  * lcrec_sinkhorn_assign.
  *   xq        device [n][e] or NULL: x_q sum, += x_res (starts from 0 unless xq_accumulate)
  *   resid_out device [n][e] or NULL: residual after the level (may alias resid_in)
- *   sse_out   device double[1] or NULL; workspace must then hold 8 KB */
+ *   sse_out   device double[1] or NULL; workspace must then hold 8 KB
+ *   ticket    NULL, or see "ticket arguments" (finishes sse_out inside the launch) */
 int lcrec_rq_apply_level(const float *resid_in, int64_t n, int e, const float *codebook, int K,
                          const int64_t *idx, int64_t idx_stride, float *xq, int xq_accumulate,
                          float *resid_out, double *sse_out, void *workspace, size_t workspace_bytes,
-                         void *stream);
+                         unsigned int *ticket, void *stream);
 
 /* Per-code count and sum of the residuals assigned to it:
  *   count[k] = #{i : idx[i*idx_stride] == k},  sum[k][:] = sum_i resid[i][:]  (item order, fp32).
@@ -257,10 +272,12 @@ int lcrec_code_stats_levels(const int64_t *idx, const float *const *resid, int64
  *   ema_count = ema_count*decay + alpha*count;  ema_sum = ema_sum*decay + alpha*sum;
  *   where ema_count > eps:  codebook = codebook*keep + (ema_sum/(ema_count+eps))*alpha.
  * decay, alpha = 1-decay and keep = 1-(1-decay) are the reference's python doubles rounded to fp32
- * by the caller. */
+ * by the caller.  skip_flag: NULL, or a device byte; when it is non-zero the call changes nothing (the sticky
+ * "loss was NaN" flag of lcrec_step_losses: the reference raises before the offending step updates anything,
+ * index/trainer.py:116, so a caller that learns of the NaN later still finds the last good state). */
 int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count,
                      const float *sum, int K, int e, float decay, float alpha, float keep, float eps,
-                     void *stream);
+                     const unsigned char *skip_flag, void *stream);
 
 /* ---- the element-wise / column-reduction half of a training step -------------------
  * Device pointers throughout; batch-sized inputs (n <= 2^20 rows); deterministic (no atomics): a column is summed by
@@ -323,13 +340,13 @@ size_t lcrec_train_reduce_workspace(void);
  * it (item-sharded data parallel): both divisions use count_total, so loss_out is this rank's share of the global
  * mean and the ranks' gradients sum to the global-batch gradient. */
 int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *grad_out,
-                          float *loss_out, void *workspace, size_t workspace_bytes, void *stream);
+                          float *loss_out, void *workspace, size_t workspace_bytes, unsigned int *ticket, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (index/trainer.py:118) on a flat gradient buffer:
  * norm_out[0] = ||grads||_2 (fp64 accumulation), norm_out[1] = min(1, max_norm / (norm + 1e-6)), the coefficient
  * lcrec_adamw_step applies. */
 int lcrec_grad_norm_clip(const float *grads, int64_t count, float max_norm, float *norm_out, void *workspace,
-                         size_t workspace_bytes, void *stream);
+                         size_t workspace_bytes, unsigned int *ticket, void *stream);
 
 /* Codebook gradient from the per-code statistics of lcrec_code_stats -- what autograd derives from the two MSE terms
  * of index/models/vq.py:90-92: grad[k][:] = (scale * (count[k]*C[k][:] - sum[k][:])) * weight, with
@@ -341,9 +358,12 @@ int lcrec_codebook_grad(const float *count, const float *sum, const float *codeb
  * (index/models/vq.py:90-92), their mean (rq.py:53), loss = recon + quant_loss_weight * rq_loss (rqvae.py:83);
  * losses_out[3] = {loss, recon, rq_loss}; sums_inout[2] += {loss, recon} (trainer.py:122-123; may be NULL);
  * *nan_flag = 1 if the loss is NaN (trainer.py:116's check as a sticky device flag; may be NULL).  sse as written by
- * lcrec_rq_assign / lcrec_rq_apply_level (device double[L]); recon a device float (lcrec_recon_loss_grad). */
+ * lcrec_rq_assign / lcrec_rq_apply_level (device double[L]); recon a device float (lcrec_recon_loss_grad).
+ * poison_probe / poison_flag (both NULL, or both given): *poison_flag = 1 when *poison_probe < 0 -- the first assignment of a
+ * batch-sized lcrec_sinkhorn_assign, which fills its output with -1 when its solver gives up; also sticky. */
 int lcrec_step_losses(const double *sse, int L, int64_t n, int e, float beta, float quant_loss_weight, const float *recon,
-                      float *losses_out, double *sums_inout, unsigned char *nan_flag, void *stream);
+                      float *losses_out, double *sums_inout, unsigned char *nan_flag, const int64_t *poison_probe,
+                      unsigned char *poison_flag, void *stream);
 
 /* Gradient reaching the encoder output z through the quantiser (autograd of vq.py:87-95 / rq.py:45-48):
  * out = (coef * (z - C0[idx0])) * weight + g_xq, coef = beta * 2/(L*n*e), weight = d loss / d rq_loss; idx0 = the
@@ -358,11 +378,13 @@ int lcrec_quantizer_input_grad(const float *z, const float *codebook0, const int
  *   total_steps (transformers' get_{constant,linear}_schedule_with_warmup multipliers, in double).
  * *step (device int64) = optimiser steps taken so far; the call uses lr(*step) and bias corrections for step *step+1,
  * then increments it -- so a captured hipGraph of a training step replays without any host-side scalar.
- * lr_out: device float receiving the learning rate used, or NULL. */
+ * lr_out: device float receiving the learning rate used, or NULL.
+ * ticket: NULL, or see "ticket arguments": the increment is then made by the last workgroup of the update launch.
+ * skip_flag: NULL, or a device byte; non-zero = update nothing and leave *step (see lcrec_ema_update). */
 int lcrec_adamw_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, const float *clip,
                      int64_t *step, double base_lr, double beta1, double beta2, double eps, double weight_decay,
                      int decoupled, int schedule, int64_t warmup_steps, int64_t total_steps, float *lr_out,
-                     void *stream);
+                     unsigned int *ticket, const unsigned char *skip_flag, void *stream);
 
 /* Which items share an identical index tuple.  Replaces the Python string-set / dict passes of
  * index/trainer.py:139-150 (collision rate) and index/generate_indices.py:18-42

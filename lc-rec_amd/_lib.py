@@ -37,8 +37,8 @@ _SIGNATURES = {
     "lcrec_context_destroy": (ctypes.c_int, [_vp]),
     "lcrec_context_set_pipelines": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lcrec_rq_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
-                                       ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_float,
-                                       _vp, ctypes.c_size_t, _vp]),
+                                       ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_float,
+                                       _vp, ctypes.c_size_t, _vp, _vp]),
     "lcrec_encode_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                                         ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "lcrec_encode_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
@@ -50,16 +50,16 @@ _SIGNATURES = {
                                                           ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
     "lcrec_sinkhorn_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int,
                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_double,
-                                             ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_size_t, _vp, _vp]),
+                                             ctypes.c_int, _vp, ctypes.c_int64, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "lcrec_rq_apply_level": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int, _vp,
-                                            ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+                                            ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp, _vp]),
     "lcrec_code_stats": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                         _vp, _vp, _vp]),
     "lcrec_code_stats_levels": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                                ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                                ctypes.POINTER(_vp), ctypes.c_float, ctypes.c_float, _vp]),
     "lcrec_ema_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
-                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "lcrec_bn_relu_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp,
                                              _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
     "lcrec_bn_relu_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _vp,
@@ -73,16 +73,17 @@ _SIGNATURES = {
                                                ctypes.c_float, _vp, _vp, _vp]),
     "lcrec_relu_bias_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "lcrec_train_reduce_workspace": (ctypes.c_size_t, []),
-    "lcrec_recon_loss_grad": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
-    "lcrec_grad_norm_clip": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
+    "lcrec_recon_loss_grad": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_size_t, _vp,
+                                             _vp]),
+    "lcrec_grad_norm_clip": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp, _vp]),
     "lcrec_codebook_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "lcrec_step_losses": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp,
-                                         _vp, _vp]),
+                                         _vp, _vp, _vp, _vp]),
     "lcrec_quantizer_input_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_float, _vp, _vp, _vp]),
     "lcrec_adamw_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_int64, ctypes.c_int64, _vp, _vp]),
+                                        ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "lcrec_collision_groups_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "lcrec_collision_groups": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _vp,
                                               _vp, _vp, _vp, ctypes.c_size_t, _vp]),
@@ -104,7 +105,7 @@ class TraceEntry(ctypes.Structure):
 
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 2                      # LCREC_ABI_VERSION of include/lcrec.h this binding was written against
+ABI_VERSION = 3                      # LCREC_ABI_VERSION of include/lcrec.h this binding was written against
 
 _lib = None
 

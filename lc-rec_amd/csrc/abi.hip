@@ -204,12 +204,12 @@ LCREC_API size_t lcrec_rq_assign_workspace(int64_t n, int e, const int *K, int L
 }
 
 LCREC_API int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-                              int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out,
+                              int64_t *idx_out, int64_t idx_stride, float *xq_out, int xq_accumulate, double *sse_out,
                               float *resid_out, float *margin_out, uint32_t *neartie_out, float tie_tau,
-                              void *workspace, size_t workspace_bytes, void *stream)
+                              void *workspace, size_t workspace_bytes, unsigned int *ticket, void *stream)
 {
-    return rq_assign(z, n, e, codebooks, K, L, idx_out, xq_out, xq_accumulate, sse_out, resid_out, margin_out,
-                     neartie_out, tie_tau, workspace, workspace_bytes, (hipStream_t)stream);
+    return rq_assign(z, n, e, codebooks, K, L, idx_out, idx_stride, xq_out, xq_accumulate, sse_out, resid_out, margin_out,
+                     neartie_out, tie_tau, workspace, workspace_bytes, ticket, (hipStream_t)stream);
 }
 
 LCREC_API size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n_layers, const int *K, int L)
@@ -279,8 +279,8 @@ LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, in
             }
         }
     }
-    return rq_assign(latent, n, e, codebooks, K, L, idx_out, xq_out, 0, sse_out, nullptr, margin_out, neartie_out, tie_tau,
-                     rq_ws, o.rq_bytes, s);
+    return rq_assign(latent, n, e, codebooks, K, L, idx_out, L, xq_out, 0, sse_out, nullptr, margin_out, neartie_out, tie_tau,
+                     rq_ws, o.rq_bytes, nullptr, s);
 }
 
 LCREC_API int lcrec_trace_enable(int on)
@@ -324,19 +324,19 @@ LCREC_API size_t lcrec_sinkhorn_assign_workspace(int64_t n, int K, const int64_t
 LCREC_API int lcrec_sinkhorn_assign(const float *resid, int64_t n, int e, const float *codebook, int K,
                                     const int64_t *group_offsets, int n_groups, double epsilon, int iters,
                                     int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                                    lcrec_context *ctx, void *stream)
+                                    lcrec_context *ctx, unsigned int *ticket, void *stream)
 {
     return sinkhorn_assign(resid, n, e, codebook, K, group_offsets, n_groups, epsilon, iters, idx_out, idx_stride,
-                           workspace, workspace_bytes, ctx, (hipStream_t)stream);
+                           workspace, workspace_bytes, ctx, ticket, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_rq_apply_level(const float *resid_in, int64_t n, int e, const float *codebook, int K,
                                    const int64_t *idx, int64_t idx_stride, float *xq, int xq_accumulate,
                                    float *resid_out, double *sse_out, void *workspace, size_t workspace_bytes,
-                                   void *stream)
+                                   unsigned int *ticket, void *stream)
 {
     return apply_level(resid_in, n, e, codebook, K, idx, idx_stride, xq, xq_accumulate, resid_out, sse_out, workspace,
-                       workspace_bytes, (hipStream_t)stream);
+                       workspace_bytes, ticket, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K,
@@ -347,9 +347,9 @@ LCREC_API int lcrec_code_stats(const int64_t *idx, int64_t idx_stride, const flo
 
 LCREC_API int lcrec_ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count,
                                const float *sum, int K, int e, float decay, float alpha, float keep, float eps,
-                               void *stream)
+                               const unsigned char *skip_flag, void *stream)
 {
-    return ema_update(ema_count, ema_sum, codebook, count, sum, K, e, decay, alpha, keep, eps, (hipStream_t)stream);
+    return ema_update(ema_count, ema_sum, codebook, count, sum, K, e, decay, alpha, keep, eps, skip_flag, (hipStream_t)stream);
 }
 
 LCREC_API int64_t lcrec_index_json_bound(int64_t n, int L) { return index_json_bound(n, L); }
@@ -394,24 +394,24 @@ LCREC_API int lcrec_relu_bias_backward(const float *gy, const float *y, int64_t 
 LCREC_API size_t lcrec_train_reduce_workspace(void) { return train_reduce_workspace(); }
 
 LCREC_API int lcrec_recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *grad_out,
-                                    float *loss_out, void *workspace, size_t workspace_bytes, void *stream)
+                                    float *loss_out, void *workspace, size_t workspace_bytes, unsigned int *ticket, void *stream)
 {
-    return recon_loss_grad(out, x, count, count_total, l1, grad_out, loss_out, workspace, workspace_bytes, (hipStream_t)stream);
+    return recon_loss_grad(out, x, count, count_total, l1, grad_out, loss_out, workspace, workspace_bytes, ticket, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_grad_norm_clip(const float *grads, int64_t count, float max_norm, float *norm_out, void *workspace,
-                                   size_t workspace_bytes, void *stream)
+                                   size_t workspace_bytes, unsigned int *ticket, void *stream)
 {
-    return grad_norm_clip(grads, count, max_norm, norm_out, workspace, workspace_bytes, (hipStream_t)stream);
+    return grad_norm_clip(grads, count, max_norm, norm_out, workspace, workspace_bytes, ticket, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_adamw_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, const float *clip,
                                int64_t *step, double base_lr, double beta1, double beta2, double eps, double weight_decay,
                                int decoupled, int schedule, int64_t warmup_steps, int64_t total_steps, float *lr_out,
-                               void *stream)
+                               unsigned int *ticket, const unsigned char *skip_flag, void *stream)
 {
     return adamw_step(params, grads, exp_avg, exp_avg_sq, count, clip, step, base_lr, beta1, beta2, eps, weight_decay, decoupled,
-                      schedule, warmup_steps, total_steps, lr_out, (hipStream_t)stream);
+                      schedule, warmup_steps, total_steps, lr_out, ticket, skip_flag, (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_codebook_grad(const float *count, const float *sum, const float *codebook, int K, int e, float scale,
@@ -465,9 +465,11 @@ LCREC_API int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, in
 }
 
 LCREC_API int lcrec_step_losses(const double *sse, int L, int64_t n, int e, float beta, float quant_loss_weight, const float *recon,
-                                float *losses_out, double *sums_inout, unsigned char *nan_flag, void *stream)
+                                float *losses_out, double *sums_inout, unsigned char *nan_flag, const int64_t *poison_probe,
+                                unsigned char *poison_flag, void *stream)
 {
-    return step_losses(sse, L, n, e, beta, quant_loss_weight, recon, losses_out, sums_inout, nan_flag, (hipStream_t)stream);
+    return step_losses(sse, L, n, e, beta, quant_loss_weight, recon, losses_out, sums_inout, nan_flag, poison_probe, poison_flag,
+                       (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_quantizer_input_grad(const float *z, const float *codebook0, const int64_t *idx, int64_t idx_stride, int64_t n,

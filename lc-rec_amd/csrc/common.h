@@ -97,6 +97,45 @@ struct ForkJoin {
     ForkJoin &operator=(const ForkJoin &) = delete;
 };
 
+// ---- "the last workgroup to arrive finishes the reduction" (include/lcrec.h, `ticket` arguments) -----------------------------
+// Every workgroup hands its partial over with agent-scope (write-through) atomic stores made by ONE thread, that thread waits
+// for them (vmcnt) and takes a ticket with a relaxed agent-scope add; the workgroup whose add returns count-1 is the last: it
+// resets the ticket, and reads all partials back with agent-scope atomic loads behind an acquire.  No agent-scope RELEASE
+// anywhere -- on gfx950 that writes the XCD's dirty L2 lines back (MI355X_MICROARCH.md, Valid forms; measured here at 38 us
+// with 8 MB dirty) -- and nothing spins: the launch cannot deadlock whatever the dispatch order.
+#ifdef __HIPCC__
+__device__ __forceinline__ void handoff_put(double *slot, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double handoff_get(const double *slot)
+{
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(slot), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void handoff_put(float *slot, float v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned *>(slot), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float handoff_get(const float *slot)
+{
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned *>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// Call from the ONE thread that made this workgroup's handoff_put stores (if other threads stored too: after their own
+// `s_waitcnt vmcnt(0)` and a workgroup barrier).  True in exactly one workgroup of the launch: the one that arrived last.
+__device__ __forceinline__ bool ticket_is_last(unsigned *ticket, unsigned workgroups)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1u != workgroups) return false;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // left zero for the next call
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return true;
+}
+#endif
+
 // LCREC_OK when ctx is NULL or belongs to the current device
 int check_context(const lcrec_context *ctx, const char *who);
 
@@ -115,17 +154,17 @@ int linear_backward_weights(const lcrec_dw_problem *problems, int count, void *w
 
 size_t rq_assign_workspace(int64_t n, int e, const int *K, int L);
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-              int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
+              int64_t *idx_out, int64_t idx_stride, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
               float *margin_out, uint32_t *neartie_out, float tie_tau,
-              void *workspace, size_t workspace_bytes, hipStream_t stream);
+              void *workspace, size_t workspace_bytes, unsigned *ticket, hipStream_t stream);
 
 size_t sinkhorn_workspace(int64_t n, int K, const int64_t *offs, int G);
 int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
                     int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                    lcrec_context *ctx, hipStream_t stream);
+                    lcrec_context *ctx, unsigned *ticket, hipStream_t stream);
 int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, const int64_t *idx, int64_t idx_stride,
                 float *xq, int xq_accumulate, float *r_out, double *sse_out, void *workspace, size_t workspace_bytes,
-                hipStream_t stream);
+                unsigned *ticket, hipStream_t stream);
 int code_stats(const int64_t *idx, int64_t idx_stride, const float *resid, int64_t n, int e, int K, float *count,
                float *sum, hipStream_t stream);
 int code_stats_levels(const int64_t *idx, const float *const *resid, int64_t n, int e, const int *K, int L, float *const *count,
@@ -134,7 +173,7 @@ size_t collision_workspace(int64_t n, int L);
 int collision_groups(const int64_t *idx, int64_t n, int L, const int *K, int64_t *members_out, int64_t *offsets_out,
                      int64_t *counters_out, void *workspace, size_t workspace_bytes, hipStream_t stream);
 int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,
-               float decay, float alpha, float keep, float eps, hipStream_t stream);
+               float decay, float alpha, float keep, float eps, const unsigned char *skip, hipStream_t stream);
 
 // training-step element-wise / reduction kernels (train_ops.hip)
 int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const float *beta, float eps, float momentum,
@@ -155,18 +194,18 @@ int bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n
 int relu_bias_backward(const float *gy, const float *y, int64_t n, int F, int relu, float *g_out, float *dbias, hipStream_t stream);
 size_t train_reduce_workspace();
 int recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *g, float *loss,
-                    void *workspace, size_t workspace_bytes, hipStream_t stream);
+                    void *workspace, size_t workspace_bytes, unsigned *ticket, hipStream_t stream);
 int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_out, void *workspace, size_t workspace_bytes,
-                   hipStream_t stream);
+                   unsigned *ticket, hipStream_t stream);
 int step_losses(const double *sse, int L, int64_t n, int e, float beta, float qlw, const float *recon, float *out3, double *sums2,
-                unsigned char *nan_flag, hipStream_t stream);
+                unsigned char *nan_flag, const int64_t *probe, unsigned char *probe_flag, hipStream_t stream);
 int quantizer_input_grad(const float *z, const float *cb0, const int64_t *idx, int64_t idx_stride, int64_t n, int e, float coef,
                          float weight, const float *g_xq, float *out, hipStream_t stream);
 int codebook_grad(const float *count, const float *sum, const float *cb, int K, int e, float scale, float weight, float *grad,
                   hipStream_t stream);
 int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const float *clip, int64_t *step, double base_lr,
                double beta1, double beta2, double eps, double weight_decay, int decoupled, int schedule, int64_t warmup_steps,
-               int64_t total_steps, float *lr_out, hipStream_t stream);
+               int64_t total_steps, float *lr_out, unsigned *ticket, const unsigned char *skip, hipStream_t stream);
 
 // host-side text (index_json.hip)
 int64_t index_json_bound(int64_t n, int L);

@@ -42,7 +42,10 @@ struct RqParams {
     int row_off[LCREC_MAX_LEVELS];  // first LDS row of a level; a level occupies K rounded up to 32 rows
     int rows;                       // total (padded) rows staged by this launch
     int xq_accumulate;              // xq holds an initial value to add to (else starts at 0)
-    int64_t *idx_out;      // [n][L]
+    int64_t *idx_out;      // [n][L] with row stride idx_stride (>= L) elements
+    int64_t idx_stride;
+    unsigned *ticket;      // with it the last workgroup to arrive adds the SSE partials (include/lcrec.h); else a second launch
+    double *sse_out;       // [L] (ticket form)
     float *xq;             // [n][E] in/out (read when l0 > 0), or NULL
     float *resid_next;     // [n][E] residual after level l1-1, or NULL
     float *resid_levels;   // [L+1][n][E]: entry l = residual entering level l, entry L = final residual; or NULL
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
                 }
             }
 
-            if (valid && writer) p.idx_out[item * p.L + l] = (int64_t)bi;
+            if (valid && writer) p.idx_out[item * p.idx_stride + l] = (int64_t)bi;
             if (WANT_MARGIN) {
                 const float margin = second - win;
                 if (p.margin && valid && writer) p.margin[item * p.L + l] = margin;
@@ -342,10 +345,29 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
 
     if (p.sse_partial) {
         __syncthreads();
-        for (int l = p.l0 + tid; l < p.l1; l += THREADS) {
-            double v = 0.0;
-            for (int w = 0; w < WAVES; ++w) v += wave_sse[w * p.L + l];
-            p.sse_partial[(size_t)blockIdx.x * p.L + l] = v;
+        if (!p.ticket) {
+            for (int l = p.l0 + tid; l < p.l1; l += THREADS) {
+                double v = 0.0;
+                for (int w = 0; w < WAVES; ++w) v += wave_sse[w * p.L + l];
+                p.sse_partial[(size_t)blockIdx.x * p.L + l] = v;
+            }
+            return;
+        }
+        // ticket form: thread 0 publishes all of the workgroup's level sums (L <= 16), takes the ticket, and in the last
+        // workgroup to arrive adds every workgroup's partials in workgroup order -- rq_sse_finalize_kernel's sums, its bits
+        if (tid == 0) {
+            for (int l = p.l0; l < p.l1; ++l) {
+                double v = 0.0;
+                for (int w = 0; w < WAVES; ++w) v += wave_sse[w * p.L + l];
+                handoff_put(p.sse_partial + (size_t)blockIdx.x * p.L + l, v);
+            }
+            if (ticket_is_last(p.ticket, gridDim.x)) {
+                for (int l = p.l0; l < p.l1; ++l) {
+                    double v = 0.0;
+                    for (unsigned b = 0; b < gridDim.x; ++b) v += handoff_get(p.sse_partial + (size_t)b * p.L + l);
+                    p.sse_out[l] = v;
+                }
+            }
         }
     }
 }
@@ -428,13 +450,15 @@ static int dispatch(const RqParams &p, int threads, int grid, size_t lds, bool w
 }
 
 int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const int *K, int L,
-              int64_t *idx_out, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
+              int64_t *idx_out, int64_t idx_stride, float *xq_out, int xq_accumulate, double *sse_out, float *resid_out,
               float *margin_out, uint32_t *neartie_out, float tie_tau,
-              void *workspace, size_t workspace_bytes, hipStream_t stream)
+              void *workspace, size_t workspace_bytes, unsigned *ticket, hipStream_t stream)
 {
     if (n == 0 && K && L >= 1 && L <= LCREC_MAX_LEVELS) return LCREC_OK;   // empty batch
     if (!z || !codebooks || !K || !idx_out) return fail(LCREC_EINVAL, "rq_assign: NULL pointer");
     if (n < 0 || L < 1 || L > LCREC_MAX_LEVELS) return fail(LCREC_EINVAL, "rq_assign: bad n=%lld or L=%d", (long long)n, L);
+    if (idx_stride == 0) idx_stride = L;
+    if (idx_stride < L) return fail(LCREC_EINVAL, "rq_assign: idx_stride %lld < L=%d", (long long)idx_stride, L);
     if (neartie_out && !(tie_tau >= 0.0f)) return fail(LCREC_EINVAL, "rq_assign: tie_tau must be >= 0");
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e_dim=%d (supported: 16, 32, 64)", e);
     if (((uintptr_t)z | (uintptr_t)codebooks | (uintptr_t)xq_out | (uintptr_t)resid_out) & 15)
@@ -485,6 +509,9 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
         p.cb = codebooks;
         p.n = n; p.l0 = l0; p.l1 = l1; p.L = L; p.rows = rows;
         p.idx_out = idx_out;
+        p.idx_stride = idx_stride;
+        p.ticket = sse_out ? ticket : nullptr;
+        p.sse_out = sse_out;
         p.xq = xq_out;
         p.resid_levels = resid_out;
         p.sse_partial = sse_out ? partial : nullptr;
@@ -501,7 +528,7 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
         else if (e == 32) rc = dispatch<32>(p, threads, grid, lds, xq_out != nullptr, stream);
         else rc = dispatch<64>(p, threads, grid, lds, xq_out != nullptr, stream);
         if (rc) return rc;
-        if (sse_out) {
+        if (sse_out && !ticket) {
             TraceScope trace(K_RQ_SSE_FINALIZE, stream);
             hipLaunchKernelGGL(rq_sse_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, grid, L, l0, l1, sse_out);
             rc = check_launch("rq_sse_finalize_kernel");

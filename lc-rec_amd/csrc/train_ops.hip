@@ -399,12 +399,36 @@ __device__ __forceinline__ double block_sum(double v, double *sm)
     return s;                              // valid in thread 0
 }
 
+// Sum of `blocks` per-workgroup partials in the finishing kernels' order (thread i adds partials i, i + 256, ...; then the
+// workgroup tree) -- shared by the second-launch form and by the last-workgroup form, so both give the same bits.
+template <bool HANDOFF>
+__device__ __forceinline__ double sum_partials_ordered(const double *partial, int blocks, double *sm)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += RED_THREADS) acc += HANDOFF ? handoff_get(partial + i) : partial[i];
+    return block_sum(acc, sm);            // valid in thread 0
+}
+
+// `ticket` form of a partial-sum kernel's tail: thread 0 publishes the workgroup's partial and takes a ticket; returns true
+// (in every thread) in the workgroup that arrived last.
+__device__ __forceinline__ bool publish_and_check_last(double *partial, double s, unsigned *ticket, int *last_sh)
+{
+    if (threadIdx.x == 0) {
+        handoff_put(partial + blockIdx.x, s);
+        *last_sh = ticket_is_last(ticket, gridDim.x) ? 1 : 0;
+    }
+    __syncthreads();
+    return *last_sh != 0;
+}
+
 // mse: loss = mean (out - x)^2, g = 2 (out - x) / count;  l1: loss = mean |out - x|, g = sign(out - x) / count
 __global__ __launch_bounds__(RED_THREADS) void recon_loss_grad_kernel(const float *__restrict__ out, const float *__restrict__ x,
                                                                        int64_t count, int64_t count_total, int l1,
-                                                                       float *__restrict__ g, double *partial)
+                                                                       float *__restrict__ g, double *partial, unsigned *ticket,
+                                                                       float *loss)
 {
     __shared__ double sm[RED_THREADS / 64];
+    __shared__ int last_sh;
     const float scale = (l1 ? 1.0f : 2.0f) / (float)count_total;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < count; i += (int64_t)gridDim.x * RED_THREADS) {
@@ -418,44 +442,67 @@ __global__ __launch_bounds__(RED_THREADS) void recon_loss_grad_kernel(const floa
         }
     }
     const double s = block_sum(acc, sm);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    if (!ticket) {
+        if (threadIdx.x == 0) partial[blockIdx.x] = s;
+        return;
+    }
+    if (!publish_and_check_last(partial, s, ticket, &last_sh)) return;
+    const double total = sum_partials_ordered<true>(partial, gridDim.x, sm);
+    if (threadIdx.x == 0) *loss = (float)(total / (double)count_total);
 }
 
 __global__ __launch_bounds__(RED_THREADS) void recon_loss_finish_kernel(const double *partial, int blocks, int64_t count, float *loss)
 {
     __shared__ double sm[RED_THREADS / 64];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < blocks; i += RED_THREADS) acc += partial[i];
-    const double s = block_sum(acc, sm);
+    const double s = sum_partials_ordered<false>(partial, blocks, sm);
     if (threadIdx.x == 0) *loss = (float)(s / (double)count);
 }
 
-__global__ __launch_bounds__(RED_THREADS) void sumsq_kernel(const float *__restrict__ g, int64_t count, double *partial)
+__device__ __forceinline__ void norm_and_coef(double sumsq, float max_norm, float *norm_out)
+{
+    const float norm = (float)__builtin_sqrt(sumsq);
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+    norm_out[0] = norm;
+    norm_out[1] = coef;
+}
+
+// 16-byte loads (the flat gradient buffer is 256-byte aligned; a ragged tail is read by scalars): 35 MB at 768-d in ~7 us
+__global__ __launch_bounds__(RED_THREADS) void sumsq_kernel(const float *__restrict__ g, int64_t count, double *partial, unsigned *ticket,
+                                                             float max_norm, float *norm_out)
 {
     __shared__ double sm[RED_THREADS / 64];
+    __shared__ int last_sh;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < count; i += (int64_t)gridDim.x * RED_THREADS) {
+    const int64_t count4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? count / 4 : 0;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < count4; i += (int64_t)gridDim.x * RED_THREADS) {
+        const f32x4 v = g4[i];
+        acc += (double)v[0] * (double)v[0];
+        acc += (double)v[1] * (double)v[1];
+        acc += (double)v[2] * (double)v[2];
+        acc += (double)v[3] * (double)v[3];
+    }
+    for (int64_t i = count4 * 4 + (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < count; i += (int64_t)gridDim.x * RED_THREADS) {
         const double v = (double)g[i];
         acc += v * v;
     }
     const double s = block_sum(acc, sm);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    if (!ticket) {
+        if (threadIdx.x == 0) partial[blockIdx.x] = s;
+        return;
+    }
+    if (!publish_and_check_last(partial, s, ticket, &last_sh)) return;
+    const double total = sum_partials_ordered<true>(partial, gridDim.x, sm);
+    if (threadIdx.x == 0) norm_and_coef(total, max_norm, norm_out);
 }
 
 // norm_out[0] = ||g||_2, norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
 __global__ __launch_bounds__(RED_THREADS) void grad_norm_finish_kernel(const double *partial, int blocks, float max_norm, float *norm_out)
 {
     __shared__ double sm[RED_THREADS / 64];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < blocks; i += RED_THREADS) acc += partial[i];
-    const double s = block_sum(acc, sm);
-    if (threadIdx.x == 0) {
-        const float norm = (float)__builtin_sqrt(s);
-        float coef = max_norm / (norm + 1e-6f);
-        coef = coef > 1.0f ? 1.0f : coef;
-        norm_out[0] = norm;
-        norm_out[1] = coef;
-    }
+    const double s = sum_partials_ordered<false>(partial, blocks, sm);
+    if (threadIdx.x == 0) norm_and_coef(s, max_norm, norm_out);
 }
 
 struct AdamParams {
@@ -468,6 +515,8 @@ struct AdamParams {
     int schedule;            // 0 = constant after warm-up, 1 = linear decay to 0 at total_steps, -1 = no schedule (lr = base_lr)
     int64_t warmup_steps, total_steps;
     float *lr_out;           // device float: the learning rate this step used (logging / tests), or NULL
+    unsigned *ticket;        // with it the LAST workgroup to finish advances *step (no second launch)
+    const unsigned char *skip;   // device flag (a sticky "loss was NaN"): when set, nothing is updated and *step stays
 };
 
 // learning rate of optimiser step `s` (0-based): base_lr * lambda(s), the python-double arithmetic of
@@ -493,6 +542,7 @@ __device__ __forceinline__ double lr_at(const AdamParams &a, int64_t s)
 // as clip_grad_norm_ leaves it).
 __global__ __launch_bounds__(256) void adamw_step_kernel(AdamParams a)
 {
+    const bool skip = a.skip && *a.skip;              // uniform over the launch
     const int64_t s = *a.step;                       // steps taken before this one
     const double lr = lr_at(a, s);
     const double t = (double)(s + 1);
@@ -500,34 +550,43 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(AdamParams a)
     const double bc2_sqrt = sqrt(1.0 - pow(a.beta2, t));
     const float coef = a.clip ? a.clip[1] : 1.0f;
     const float step_size = (float)(lr / bc1);
-    const float b1 = (float)a.beta1, b2 = (float)a.beta2, one_m_b1 = (float)(1.0 - a.beta1), one_m_b2 = (float)(1.0 - a.beta2);
+    const float b2 = (float)a.beta2, one_m_b1 = (float)(1.0 - a.beta1), one_m_b2 = (float)(1.0 - a.beta2);
     const float epsf = (float)a.eps, bc2s = (float)bc2_sqrt;
     const float decay = (float)(lr * a.weight_decay), wd = (float)a.weight_decay;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * 256) {
-        float p = a.p[i], g = a.g[i] * coef, m = a.m[i], v = a.v[i];
-        a.g[i] = g;
-        if (a.weight_decay != 0.0) {
-            if (a.decoupled) p -= decay * p;
-            else g += p * wd;
+    if (!skip) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * 256) {
+            float p = a.p[i], g = a.g[i] * coef, m = a.m[i], v = a.v[i];
+            a.g[i] = g;
+            if (a.weight_decay != 0.0) {
+                if (a.decoupled) p -= decay * p;
+                else g += p * wd;
+            }
+            m = m + one_m_b1 * (g - m);                  // lerp(m, g, 1 - beta1)
+            v = b2 * v + one_m_b2 * g * g;
+            const float denom = __builtin_sqrtf(v) / bc2s + epsf;
+            p -= step_size * m / denom;
+            a.p[i] = p; a.m[i] = m; a.v[i] = v;
         }
-        m = m + one_m_b1 * (g - m);                  // lerp(m, g, 1 - beta1)
-        v = b2 * v + one_m_b2 * g * g;
-        const float denom = __builtin_sqrtf(v) / bc2s + epsf;
-        p -= step_size * m / denom;
-        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.lr_out) *a.lr_out = (float)lr;
     }
-    (void)b1;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.lr_out) *a.lr_out = (float)lr;
+    if (a.ticket) {
+        // every workgroup read *step on entry; the one that finishes last -- after all the others have taken their tickets,
+        // i.e. are past that read -- advances it
+        __syncthreads();
+        if (threadIdx.x == 0 && ticket_is_last(a.ticket, gridDim.x) && !skip) *a.step = s + 1;
+    }
 }
 
-__global__ void step_advance_kernel(int64_t *step) { *step += 1; }
+__global__ void step_advance_kernel(int64_t *step, const unsigned char *skip) { if (!(skip && *skip)) *step += 1; }
 
 // The scalar tail of a step, one thread: level losses and their mean (vq.py:90-92, rq.py:53), total loss (rqvae.py:83),
 // the trainer's running sums (trainer.py:122-123) and its NaN check (trainer.py:116) as a sticky device flag.
 __global__ void step_losses_kernel(const double *sse, int L, double count, float beta, float qlw, const float *recon,
-                                   float *out3, double *sums2, unsigned char *nan_flag)
+                                   float *out3, double *sums2, unsigned char *nan_flag, const int64_t *probe,
+                                   unsigned char *probe_flag)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (probe && probe_flag && *probe < 0) *probe_flag = 1;     // a poisoned (-1) Sinkhorn assignment: the solver gave up
     float acc = 0.f;
     for (int l = 0; l < L; ++l) {
         const float mse = (float)(sse[l] / count);
@@ -706,7 +765,7 @@ static int red_blocks(int64_t count)
 size_t train_reduce_workspace() { return RED_MAX_BLOCKS * sizeof(double); }
 
 int recon_loss_grad(const float *out, const float *x, int64_t count, int64_t count_total, int l1, float *g, float *loss,
-                    void *workspace, size_t workspace_bytes, hipStream_t stream)
+                    void *workspace, size_t workspace_bytes, unsigned *ticket, hipStream_t stream)
 {
     if (count_total == 0) count_total = count;
     if (count_total < count) return fail(LCREC_EINVAL, "recon_loss_grad: count_total < count");
@@ -715,31 +774,35 @@ int recon_loss_grad(const float *out, const float *x, int64_t count, int64_t cou
     if (!workspace || workspace_bytes < train_reduce_workspace()) return fail(LCREC_EWORKSPACE, "recon_loss_grad: workspace too small");
     const int blocks = red_blocks(count);
     TraceScope trace(K_LOSS, stream);
-    hipLaunchKernelGGL(recon_loss_grad_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, out, x, count, count_total, l1, g, (double *)workspace);
-    hipLaunchKernelGGL(recon_loss_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, count_total, loss);
+    hipLaunchKernelGGL(recon_loss_grad_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, out, x, count, count_total, l1, g, (double *)workspace,
+                       ticket, loss);
+    if (!ticket)
+        hipLaunchKernelGGL(recon_loss_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, count_total, loss);
     return check_launch("recon_loss_grad_kernel");
 }
 
 int grad_norm_clip(const float *g, int64_t count, float max_norm, float *norm_out, void *workspace, size_t workspace_bytes,
-                   hipStream_t stream)
+                   unsigned *ticket, hipStream_t stream)
 {
     if (!g || !norm_out) return fail(LCREC_EINVAL, "grad_norm_clip: NULL pointer");
     if (count < 1) return fail(LCREC_EINVAL, "grad_norm_clip: empty input");
     if (!workspace || workspace_bytes < train_reduce_workspace()) return fail(LCREC_EWORKSPACE, "grad_norm_clip: workspace too small");
     const int blocks = red_blocks(count);
     TraceScope trace(K_GRAD_NORM, stream);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, g, count, (double *)workspace);
-    hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, max_norm, norm_out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, g, count, (double *)workspace, ticket, max_norm, norm_out);
+    if (!ticket)
+        hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(RED_THREADS), 0, stream, (const double *)workspace, blocks, max_norm, norm_out);
     return check_launch("grad_norm kernels");
 }
 
 int step_losses(const double *sse, int L, int64_t n, int e, float beta, float qlw, const float *recon, float *out3, double *sums2,
-                unsigned char *nan_flag, hipStream_t stream)
+                unsigned char *nan_flag, const int64_t *probe, unsigned char *probe_flag, hipStream_t stream)
 {
     if (!sse || !recon || !out3) return fail(LCREC_EINVAL, "step_losses: NULL pointer");
     if (L < 1 || L > LCREC_MAX_LEVELS || n < 1 || e < 1) return fail(LCREC_EINVAL, "step_losses: bad shape");
     TraceScope trace(K_LOSS, stream);
-    hipLaunchKernelGGL(step_losses_kernel, dim3(1), dim3(64), 0, stream, sse, L, (double)n * (double)e, beta, qlw, recon, out3, sums2, nan_flag);
+    hipLaunchKernelGGL(step_losses_kernel, dim3(1), dim3(64), 0, stream, sse, L, (double)n * (double)e, beta, qlw, recon, out3, sums2, nan_flag,
+                       probe, probe_flag);
     return check_launch("step_losses_kernel");
 }
 
@@ -769,18 +832,18 @@ int codebook_grad(const float *count, const float *sum, const float *cb, int K, 
 
 int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const float *clip, int64_t *step, double base_lr,
                double beta1, double beta2, double eps, double weight_decay, int decoupled, int schedule, int64_t warmup_steps,
-               int64_t total_steps, float *lr_out, hipStream_t stream)
+               int64_t total_steps, float *lr_out, unsigned *ticket, const unsigned char *skip, hipStream_t stream)
 {
     if (!p || !g || !m || !v || !step) return fail(LCREC_EINVAL, "adamw_step: NULL pointer");
     if (count < 1) return fail(LCREC_EINVAL, "adamw_step: empty parameter buffer");
     if (schedule < -1 || schedule > 1) return fail(LCREC_EINVAL, "adamw_step: schedule %d (supported: -1 none, 0 constant, 1 linear)", schedule);
     AdamParams a = {p, g, m, v, count, clip, step, base_lr, beta1, beta2, eps, weight_decay, decoupled, schedule, warmup_steps,
-                    total_steps, lr_out};
+                    total_steps, lr_out, ticket, skip};
     int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);
     if (blocks > 2048) blocks = 2048;
     TraceScope trace(K_ADAMW, stream);
     hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, stream, step);
+    if (!ticket) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, stream, step, skip);
     return check_launch("adamw_step_kernel");
 }
 

@@ -51,11 +51,17 @@ __device__ __forceinline__ float ord2f(unsigned u)
 
 constexpr int DIST_ITEMS = 32;   // items per block in the distance kernel
 
-// grid = (ceil(n/DIST_ITEMS), ceil(K/256)); d is [n][K]; minmax = {ord(min), ord(max)} zero/one-initialised
+constexpr int DIST_TICKET_MAX_BLOCKS = 4096;    // (min, max) partials of the ticket form: 8 bytes per workgroup
+
+// grid = (ceil(n/DIST_ITEMS), ceil(K/256)); d is [n][K]; minmax = {ord(min), ord(max)}: initialised by an earlier launch and
+// reached by atomics -- or, with a ticket (include/lcrec.h), written by the last workgroup to arrive from every workgroup's
+// partial, together with the solver's control words; the workgroups also arm the scaling solver's exchange slots then, so the
+// whole set-up of a solve is this one launch.
 template <int E>
 __global__ __launch_bounds__(256) void vq_distance_kernel(const float *__restrict__ r, int64_t n,
                                                          const float *__restrict__ cb, int K,
-                                                         float *__restrict__ d, unsigned *minmax)
+                                                         float *__restrict__ d, unsigned *minmax, unsigned *ticket,
+                                                         unsigned *mm_partial, unsigned long long *slots, int64_t slot_count)
 {
     __shared__ float rs[DIST_ITEMS][E];
     __shared__ float xs[DIST_ITEMS];
@@ -101,6 +107,27 @@ __global__ __launch_bounds__(256) void vq_distance_kernel(const float *__restric
         }
         if ((tid & 63) == 0) { red[0][tid >> 6] = f2ord(lo); red[1][tid >> 6] = f2ord(hi); }
         __syncthreads();
+        if (ticket) {
+            const unsigned nblk = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+            for (int64_t i = (int64_t)me * 256 + tid; i < slot_count; i += (int64_t)nblk * 256) slots[i] = ~0ull;   // SKP_EMPTY
+            if (tid == 0) {
+                unsigned a = red[0][0], b = red[1][0];
+                for (int w = 1; w < 4; ++w) { a = red[0][w] < a ? red[0][w] : a; b = red[1][w] > b ? red[1][w] : b; }
+                __hip_atomic_store(mm_partial + 2 * me, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mm_partial + 2 * me + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ticket_is_last(ticket, nblk)) {
+                    for (unsigned q = 0; q < nblk; ++q) {
+                        const unsigned a2 = __hip_atomic_load(mm_partial + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned b2 = __hip_atomic_load(mm_partial + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a = a2 < a ? a2 : a;
+                        b = b2 > b ? b2 : b;
+                    }
+                    minmax[0] = a; minmax[1] = b;
+                    for (int w = 2; w < 8; ++w) minmax[w] = 0u;          // barrier counter, timeout flag
+                }
+            }
+            return;
+        }
         if (tid == 0) {
             unsigned a = red[0][0], b = red[1][0];
             for (int w = 1; w < 4; ++w) { a = red[0][w] < a ? red[0][w] : a; b = red[1][w] > b ? red[1][w] : b; }
@@ -458,7 +485,7 @@ __global__ __launch_bounds__(256) void apply_level_kernel(const float *__restric
                                                          const float *__restrict__ cb, int K,
                                                          const int64_t *__restrict__ idx, int64_t idx_stride,
                                                          float *xq, int xq_accumulate, float *r_out,
-                                                         double *sse_partial)
+                                                         double *sse_partial, unsigned *ticket, double *sse_out)
 {
     __shared__ double wsum[4];
     const int per = e / 4;
@@ -490,7 +517,20 @@ __global__ __launch_bounds__(256) void apply_level_kernel(const float *__restric
         part = wave_sum(part);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
         __syncthreads();
-        if (threadIdx.x == 0) sse_partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (threadIdx.x == 0) {
+            const double mine = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (!ticket) {
+                sse_partial[blockIdx.x] = mine;
+            } else {
+                // (include/lcrec.h, `ticket`) the last workgroup to arrive adds the partials, in sum_partials_kernel's order
+                handoff_put(sse_partial + blockIdx.x, mine);
+                if (ticket_is_last(ticket, gridDim.x)) {
+                    double s = 0.0;
+                    for (unsigned b = 0; b < gridDim.x; ++b) s += handoff_get(sse_partial + b);
+                    *sse_out = s;
+                }
+            }
+        }
     }
 }
 
@@ -545,10 +585,12 @@ __global__ __launch_bounds__(256) void code_stats_kernel(const int64_t *__restri
 // index_improve/models/vq.py:155-184.  decay/alpha/keep are the reference's python-double rates
 // rounded to fp32 by the caller (alpha = 1-decay, keep = 1-(1-decay)).
 __global__ void ema_update_kernel(float *ema_count, float *ema_sum, float *codebook, const float *count,
-                                  const float *sum, int K, int e, float decay, float alpha, float keep, float eps)
+                                  const float *sum, int K, int e, float decay, float alpha, float keep, float eps,
+                                  const unsigned char *skip)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (int64_t)K * e) return;
+    if (skip && *skip) return;                  // a sticky "loss was NaN": the statistics and the codebook keep their last good state
     const int k = (int)(q / e);
     const float en = __builtin_fmaf(count[k], alpha, ema_count[k] * decay);
     const float ew = __builtin_fmaf(sum[q], alpha, ema_sum[q] * decay);
@@ -567,13 +609,14 @@ __global__ void ema_update_kernel(float *ema_count, float *ema_sum, float *codeb
 // ---------------------------------------------------------------- host launchers
 
 int vq_distances(const float *r, int64_t n, int e, const float *cb, int K, float *d, unsigned *minmax,
-                 hipStream_t stream)
+                 hipStream_t stream, unsigned *ticket = nullptr, unsigned *mm_partial = nullptr, unsigned long long *slots = nullptr,
+                 int64_t slot_count = 0)
 {
     dim3 grid((unsigned)((n + DIST_ITEMS - 1) / DIST_ITEMS), (unsigned)((K + 255) / 256));
     TraceScope trace(K_VQ_DISTANCE, stream);
-    if (e == 16) hipLaunchKernelGGL(vq_distance_kernel<16>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax);
-    else if (e == 32) hipLaunchKernelGGL(vq_distance_kernel<32>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax);
-    else if (e == 64) hipLaunchKernelGGL(vq_distance_kernel<64>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax);
+    if (e == 16) hipLaunchKernelGGL(vq_distance_kernel<16>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax, ticket, mm_partial, slots, slot_count);
+    else if (e == 32) hipLaunchKernelGGL(vq_distance_kernel<32>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax, ticket, mm_partial, slots, slot_count);
+    else if (e == 64) hipLaunchKernelGGL(vq_distance_kernel<64>, grid, dim3(256), 0, stream, r, n, cb, K, d, minmax, ticket, mm_partial, slots, slot_count);
     else return fail(LCREC_EUNSUPPORTED, "vq_distances: e_dim=%d (supported: 16, 32, 64)", e);
     return check_launch("vq_distance_kernel");
 }
@@ -582,7 +625,8 @@ static size_t sk_big_bytes(int64_t B, int K)
 {
     const int64_t nblk = (B + SK_ROWS - 1) / SK_ROWS;
     return align_up((size_t)B * K * sizeof(float), 256) + align_up((size_t)B * K * sizeof(double), 256) +
-           align_up((size_t)2 * nblk * K * sizeof(double), 256) + align_up((size_t)nblk * sizeof(double), 256) + 256;
+           align_up((size_t)2 * nblk * K * sizeof(double), 256) + align_up((size_t)nblk * sizeof(double), 256) + 256 +
+           (size_t)DIST_TICKET_MAX_BLOCKS * 2 * sizeof(unsigned);          // control words; (min, max) partials of the ticket form
 }
 
 // Size classes of a group of sz rows (see sinkhorn_assign): 0..3 = Q in LDS, allocation 16 / 32 / 64 / 128 KB (so that
@@ -1272,7 +1316,7 @@ __global__ __launch_bounds__(256) void sk_ctrl_init_kernel(unsigned *ctrl, doubl
 }
 
 static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K, double eps, int iters,
-                        int64_t *idx_out, int64_t idx_stride, char *ws, hipStream_t stream)
+                        int64_t *idx_out, int64_t idx_stride, char *ws, unsigned *ticket, hipStream_t stream)
 {
     if (K > 64 * SK_MAXC) return fail(LCREC_EUNSUPPORTED, "sinkhorn: K=%d > %d", K, 64 * SK_MAXC);
     SkBig p;
@@ -1302,9 +1346,17 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     // control words (and the scaling form's slot sentinels) by a kernel, not by memset nodes: inside a captured hipGraph
     // (engine.py) the two memsets were seen to take effect late -- replays found the previous solve's flag / a counter reset
     // under a running barrier
-    hipLaunchKernelGGL(sk_ctrl_init_kernel, dim3(scaling ? 64 : 1), dim3(256), 0, stream, minmax, p.Q, scaling ? (int64_t)3 * nblk_s * K : (int64_t)0);
-    if (int rc0 = check_launch("sk_ctrl_init_kernel")) return rc0;
-    int rc = vq_distances(r, B, e, cb, K, d, minmax, stream);
+    // With a ticket the distance launch does all of that itself (its last workgroup writes the control words).
+    const int64_t slot_count = scaling ? (int64_t)3 * nblk_s * K : (int64_t)0;
+    const int64_t dist_blocks = ((B + DIST_ITEMS - 1) / DIST_ITEMS) * ((K + 255) / 256);
+    int rc;
+    if (ticket && dist_blocks <= DIST_TICKET_MAX_BLOCKS) {
+        rc = vq_distances(r, B, e, cb, K, d, minmax, stream, ticket, minmax + 64, reinterpret_cast<unsigned long long *>(p.Q), slot_count);
+    } else {
+        hipLaunchKernelGGL(sk_ctrl_init_kernel, dim3(scaling ? 64 : 1), dim3(256), 0, stream, minmax, p.Q, slot_count);
+        if (int rc0 = check_launch("sk_ctrl_init_kernel")) return rc0;
+        rc = vq_distances(r, B, e, cb, K, d, minmax, stream);
+    }
     if (rc) return rc;
     if (iters == 0) return fail(LCREC_EUNSUPPORTED, "sinkhorn: iters must be >= 1");
     TraceScope trace(K_SINKHORN, stream);
@@ -1397,7 +1449,7 @@ __global__ void write_table_kernel(int64_t *dst, SmallTable t, int count)
 
 int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, const int64_t *offs, int G, double eps,
                     int iters, int64_t *idx_out, int64_t idx_stride, void *workspace, size_t workspace_bytes,
-                    lcrec_context *ctx, hipStream_t stream)
+                    lcrec_context *ctx, unsigned *ticket, hipStream_t stream)
 {
     if (n == 0 || G == 0) return LCREC_OK;
     if (!r || !cb || !offs || !idx_out) return fail(LCREC_EINVAL, "sinkhorn_assign: NULL pointer");
@@ -1490,7 +1542,7 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
         const int64_t sz = offs[g + 1] - offs[g];
         const int cls = sz > 0 ? sk_class(sz, K) : -1;
         if (cls == SK_BATCH || (cls == SK_SLAB && !plan.slab_ok)) {
-            int rc = sinkhorn_big(r + offs[g] * e, sz, e, cb, K, eps, iters, idx_out + offs[g] * idx_stride, idx_stride, ws, stream);
+            int rc = sinkhorn_big(r + offs[g] * e, sz, e, cb, K, eps, iters, idx_out + offs[g] * idx_stride, idx_stride, ws, ticket, stream);
             if (rc) return rc;
         }
     }
@@ -1499,7 +1551,7 @@ int sinkhorn_assign(const float *r, int64_t n, int e, const float *cb, int K, co
 
 int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, const int64_t *idx, int64_t idx_stride,
                 float *xq, int xq_accumulate, float *r_out, double *sse_out, void *workspace, size_t workspace_bytes,
-                hipStream_t stream)
+                unsigned *ticket, hipStream_t stream)
 {
     if (n == 0) return LCREC_OK;
     if (!r_in || !cb || !idx) return fail(LCREC_EINVAL, "rq_apply_level: NULL pointer");
@@ -1515,8 +1567,8 @@ int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, con
     }
     TraceScope trace(K_APPLY_LEVEL, stream);
     hipLaunchKernelGGL(apply_level_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, r_in, n, e, cb, K, idx, idx_stride, xq,
-                       xq_accumulate, r_out, partial);
-    if (sse_out) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, partial, (int)blocks, sse_out);
+                       xq_accumulate, r_out, partial, sse_out ? ticket : nullptr, sse_out);
+    if (sse_out && !ticket) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, stream, partial, (int)blocks, sse_out);
     return check_launch("apply_level_kernel");
 }
 
@@ -1721,14 +1773,14 @@ int code_stats_levels(const int64_t *idx, const float *const *resid, int64_t n, 
 }
 
 int ema_update(float *ema_count, float *ema_sum, float *codebook, const float *count, const float *sum, int K, int e,
-               float decay, float alpha, float keep, float eps, hipStream_t stream)
+               float decay, float alpha, float keep, float eps, const unsigned char *skip, hipStream_t stream)
 {
     if (!ema_count || !ema_sum || !codebook || !count || !sum) return fail(LCREC_EINVAL, "ema_update: NULL pointer");
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "ema_update: e_dim=%d (supported: 16, 32, 64)", e);
     const int64_t total = (int64_t)K * e;
     TraceScope trace(K_EMA_UPDATE, stream);
     hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ema_count, ema_sum, codebook,
-                       count, sum, K, e, decay, alpha, keep, eps);
+                       count, sum, K, e, decay, alpha, keep, eps, skip);
     return check_launch("ema_update_kernel");
 }
 

@@ -101,6 +101,21 @@ class DeviceLoader:
                                "generator on one rank only); the epoch order would not be the single-process one")
 
     def __iter__(self):
+        for lo, hi, order in self._walk():
+            yield self.data[lo:hi] if order is None else self.data.index_select(0, order[lo:hi])
+
+    def iter_selections(self):
+        """The same walk as __iter__ without materialising the batches: (matrix, row-index vector) pairs -- the captured
+        training step gathers straight into its input buffer (engine.TrainEngine.step_selected)."""
+        for lo, hi, order in self._walk():
+            if order is None:
+                if getattr(self, "_arange", None) is None:
+                    self._arange = torch.arange(self.data.shape[0], device=self.device)
+                yield self.data, self._arange[lo:hi]
+            else:
+                yield self.data, order[lo:hi]
+
+    def _walk(self):
         n = self.data.shape[0]
         if self.shuffle:
             torch.empty((), dtype=torch.int64).random_()                       # _BaseDataLoaderIter base seed
@@ -120,8 +135,4 @@ class DeviceLoader:
                 from .dist import batch_slice
                 a, b = batch_slice(hi - lo, self.rank, self.world_size)
                 lo, hi = lo + a, lo + b
-            if order is None:
-                batch = self.data[lo:hi]
-            else:
-                batch = self.data.index_select(0, order[lo:hi])
-            yield batch
+            yield lo, hi, order

@@ -33,9 +33,9 @@ chain) nothing changes at 1024 (1.80 -> 1.82) and little at 2048 (2.51 -> 2.46):
 branches' under-filled kernels side by side to any useful degree.
 
 The EMA codebook update of index_improve/ is part of the captured step (lcrec_ema_update); the steps on which a dead-code
-reset is due run eagerly.  What the engine does not cover falls back to the autograd path in trainer.py, unchanged:
-data-parallel runs, dropout > 0, activations other than ReLU, optimisers other than Adam/AdamW,
---strict_nan_check (the reference's per-step host sync).
+reset is due run eagerly.  Data-parallel runs use the same line with the exchanges in it.  What the
+engine does not cover falls back to the autograd path in trainer.py, unchanged: dropout > 0, activations other than ReLU,
+optimisers other than Adam/AdamW, --strict_nan_check (the reference's per-step host sync).
 """
 import torch
 from torch import nn
@@ -48,15 +48,19 @@ _ALIGN = 64     # floats: every parameter starts on a 256-byte boundary of the f
 
 class TrainEngine:
     def __init__(self, model, optimizer, schedule, warmup_steps, total_steps, max_norm=1.0, use_graph=True, use_ema=False,
-                 dist=None):
+                 dist=None, dp_graph="auto"):
         """schedule: "linear" | "constant" (index/trainer.py:83-92) or None (fixed learning rate).
         use_ema: the improve fork's EMA codebook update after every step (index_improve/trainer.py:119).
-        dist: an enabled dist.DistContext for item-sharded data parallel (the caller sets dist.set_batch before a step)."""
+        dist: an enabled dist.DistContext for item-sharded data parallel (the caller sets dist.set_batch before a step).
+        dp_graph: "on" captures the data-parallel step with its RCCL collectives; "off" launches the same line eagerly;
+        "auto" = on for a one-rank group (run in the GPU suite), off for more ranks -- UNVERIFIED on more than one GPU."""
         self.model = model
         self.dist = dist if (dist is not None and dist.enabled) else None
         if self.dist is not None:
             import torch.distributed as tdist
             use_graph = use_graph and tdist.get_backend() == "nccl"      # gloo collectives synchronise the host
+            if dp_graph == "off" or (dp_graph == "auto" and self.dist.world_size > 1):
+                use_graph = False
         self.collectives = 0                                                 # collectives issued or captured (tests, logs)
         self.ema_levels = [q for q in model.rq.vq_layers if use_ema and q.ema_decay is not None]
         self.optimizer = optimizer
@@ -86,6 +90,8 @@ class TrainEngine:
         self._seen = {}                                                      # batch rows -> eager steps done at that size
         self.graph_replays = 0
         self.last_idx = None
+        self._bn_counters = None                                             # BatchNorm1d.num_batches_tracked tensors ...
+        self._bn_pending = 0                                                 # ... and the steps not yet added to them
 
     # ------------------------------------------------------------------ support matrix
     @staticmethod
@@ -225,12 +231,17 @@ class TrainEngine:
         q = quantize_values(z, cbs, float(m.rq.beta), level_plan(levels, True), False, True, want_loss=False)
         self.last_idx = q["idx"]                                             # [rows, L] of the last step (a graph's static output)
         out, dec = self._mlp_forward(m.decoder, q["xq"])
-        counters = [s[2].num_batches_tracked for s in enc + dec if s[2] is not None]
-        if counters:
-            torch._foreach_add_(counters, 1)                                 # BatchNorm1d.num_batches_tracked, all layers at once
+        # (BatchNorm1d.num_batches_tracked is only ever read by checkpoints: counted on the host, written by sync_host_state)
+        if self._bn_counters is None:
+            self._bn_counters = [s[2].num_batches_tracked for s in enc + dec if s[2] is not None]
         world = self.dist
         n, e = z.shape
         works = []
+        # the Sinkhorn solver's give-up marker (a -1 assignment): tested by lcrec_step_losses itself, no launch of its own
+        probes = ops.deferred_checks.drain()
+        probe = probes[0][1] if probes else None
+        for _msg, extra in probes[1:]:                                       # (more than one Sinkhorn level: rare)
+            self.bad[1].logical_or_(extra[0] < 0)
         if world is None:
             recon, g_out = ops.recon_loss_grad(out, x, m.loss_type)
             sse = q["sse"]
@@ -243,7 +254,8 @@ class TrainEngine:
             self.collectives += 1
             sse, recon = both[:len(levels)], both[len(levels)].float()
         # level losses, their mean, the total loss, the epoch's running sums and the NaN flag: one launch
-        ops.step_losses(sse, n, e, float(m.rq.beta), m.quant_loss_weight, recon, self.last, self.sums, self.bad[0])
+        ops.step_losses(sse, n, e, float(m.rq.beta), m.quant_loss_weight, recon, self.last, self.sums, self.bad[0],
+                        poison_probe=probe, poison_flag=self.bad[1])
         dw = []
         g_xq = self._mlp_backward(dec, g_out, True, dw)
         if world is not None and self._late_span is not None:
@@ -280,29 +292,43 @@ class TrainEngine:
                 lvl.ema_step(stats[t], q["resid_in"][t])                    # counts the step, re-seeds dead codes when due
             else:
                 ops.ema_update(lvl._ema_cluster_size, lvl._ema_w, lvl.embedding.weight.data, stats[t][0], stats[t][1],
-                               lvl.ema_decay, lvl.epsilon)
+                               lvl.ema_decay, lvl.epsilon, skip_flag=self.bad[0])
         ops.grad_norm_clip(self.flat_g, self.max_norm, out=self.clip)
         ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.base_lr, self.betas, self.eps,
                        self.weight_decay, self.decoupled, clip=self.clip, schedule=self.schedule,
-                       warmup_steps=self.warmup_steps, total_steps=self.total_steps, lr_out=self.lr_used)
-        for _msg, flag in ops.deferred_checks.drain():                       # Sinkhorn poison flags of this step
-            self.bad[1].logical_or_(flag)
+                       warmup_steps=self.warmup_steps, total_steps=self.total_steps, lr_out=self.lr_used,
+                       skip_flag=self.bad[0])            # a NaN loss (sticky) leaves parameters, moments and step at the last good step
 
     # ------------------------------------------------------------------ driving it
-    def step(self, batch):
+    def step_selected(self, data, index):
+        """One training step on the rows `index` (an int64 device vector) of the device-resident matrix `data`: on a replayed
+        step the gather writes into the captured graph's input buffer (one launch instead of a gather and a copy)."""
+        rows = int(index.shape[0])
+        key = rows if self.dist is None else (rows, getattr(self.dist, "batch_rows", (None, None))[1])
+        if key in self._graphs:
+            return self.step(None, source=(data, index))
+        return self.step(data.index_select(0, index))
+
+    def step(self, batch, source=None):
         """One training step on `batch` ([rows, in_dim] on the engine's device)."""
-        rows = int(batch.shape[0])
+        rows = int(batch.shape[0]) if batch is not None else int(source[1].shape[0])
         if self.dist is not None:
             held = getattr(self.dist, "batch_rows", None)
-            if held is None or held[0] != rows:
+            if held is None or held[0] != rows:     # noqa: E129
                 raise ops._lib.LcrecError("data-parallel step: call dist.set_batch(local rows, global rows) first")
             rows = (rows, held[1])                                           # a graph per (local, global) batch shape
         self.host_steps += 1
+        self._bn_pending += 1
         # a step on which a level's dead-code reset is due (host logic, random draws, data-dependent shapes) runs eagerly
         reset_due = any((q.step_count + 1) % q.reset_interval == 0 for q in self.ema_levels)
         entry = self._graphs.get(rows)
+        if batch is None and (entry is None or reset_due):
+            batch, source = source[0].index_select(0, source[1]), None
         if entry is not None and not reset_due:
-            entry[1].copy_(batch)
+            if source is not None:
+                torch.index_select(source[0], 0, source[1], out=entry[1])    # the batch is gathered straight into the graph's input
+            else:
+                entry[1].copy_(batch)
             entry[0].replay()
             self.graph_replays += 1
             for q in self.ema_levels:
@@ -313,7 +339,7 @@ class TrainEngine:
         if not self.use_graph or done < 1 or lazy or reset_due:
             # the first step at a batch size runs eagerly: it creates the stream's workspaces, runs the one-off k-means
             # initialisation (host sklearn), and it is a real training step
-            with torch.no_grad(), ops.deferred_checks():
+            with torch.no_grad(), ops.deferred_checks(raw=True):
                 self._run(batch.contiguous(), eager=True)
             self._seen[rows] = done + 1
             return
@@ -328,22 +354,33 @@ class TrainEngine:
         mode = "thread_local" if self.dist is not None else "global"
         if self.dist is not None:
             torch.cuda.synchronize(self.device)          # (and nothing of the eager steps' collectives is left for it to poll)
+        failure = None
         try:
-            with torch.no_grad(), ops.deferred_checks():
+            with torch.no_grad(), ops.deferred_checks(raw=True):
                 with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
                     self._run(static, eager=False)
         except RuntimeError as err:
             if self.dist is None:
                 raise
-            # a collective backend that cannot be captured: keep the straight line, launched eagerly (every rank runs the
-            # same library build, so every rank ends up here)
-            import logging
-            logging.getLogger().warning("lcrec_amd.engine: data-parallel step not capturable (%s); running it eagerly", err)
-            self.use_graph = False
+            failure = err
+        if self.dist is not None:
+            # a collective backend that cannot be captured: keep the straight line, launched eagerly.  Every rank must
+            # take the same path -- a rank replaying a graph while a peer launches eagerly would still pair up collective
+            # for collective, but one rank falling back alone is not a state worth reasoning about -- so the ranks agree
+            # on the outcome (a capture records, it does not execute: nobody is inside a collective here)
             torch.cuda.synchronize(self.device)
-            with torch.no_grad(), ops.deferred_checks():
-                self._run(batch.contiguous(), eager=True)
-            return
+            ok = torch.tensor([0.0 if failure is not None else 1.0], dtype=torch.float32, device=self.device)
+            self.dist.all_reduce_(ok)
+            if float(ok.item()) < self.dist.world_size:
+                import logging
+                logging.getLogger().warning("lcrec_amd.engine: data-parallel step not capturable on every rank (%s); running "
+                                            "it eagerly", failure if failure is not None else "a peer's capture failed")
+                self.use_graph = False
+                del graph
+                with torch.no_grad(), ops.deferred_checks(raw=True):
+                    self._run(batch.contiguous(), eager=True)
+                self._seen[rows] = done + 1
+                return
         self._graphs[rows] = (graph, static)
         graph.replay()                                                       # capture records, replay executes: this step
         self.graph_replays += 1
@@ -370,6 +407,9 @@ class TrainEngine:
         """Make what the host can see agree with the device: the optimizer's per-parameter `step` entries (checkpoints)
         and the LambdaLR scheduler's counters and `lr` (logging, get_last_lr)."""
         self._step_f32.fill_(float(self.host_steps))
+        if self._bn_pending and self._bn_counters:
+            torch._foreach_add_(self._bn_counters, self._bn_pending)
+        self._bn_pending = 0
         if scheduler is not None and scheduler.last_epoch != self.host_steps:
             scheduler.last_epoch = self.host_steps
             scheduler._step_count = self.host_steps + 1

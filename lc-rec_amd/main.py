@@ -73,6 +73,10 @@ def parse_args(argv=None):
     parser.add_argument("--train_engine", type=str, default="auto", choices=["auto", "off"],
                         help="auto = run the training step as one captured hipGraph when the configuration allows it "
                              "(lcrec_amd.engine); off = always the autograd path")
+    parser.add_argument("--dp_graph", type=str, default="auto", choices=["auto", "on", "off"],
+                        help="data-parallel runs: capture the step WITH its RCCL collectives into the hipGraph (on), or launch "
+                             "the same straight line eagerly (off).  auto = off for more than one rank: the captured "
+                             "multi-rank step has not been run on more than one GPU yet (DESIGN.md section 6)")
     parser.add_argument("--kmeans_impl", type=str, default="sklearn", choices=["sklearn", "device"],
                         help="sklearn = the reference's host KMeans call; device = k-means++/Lloyd in HBM")
     args = parser.parse_args(argv)

@@ -84,6 +84,25 @@ def _workspace(nbytes, device):
 
 def release_workspaces():
     _workspaces.clear()
+    _tickets.clear()
+
+
+# `ticket` arguments of include/lcrec.h: one zeroed 4-byte word per (device, stream) -- every call leaves it zero, and calls on
+# one stream are ordered, so they can all share it.  LCREC_TICKETS=0 (diagnostic): the two-launch forms.
+_tickets = {}
+USE_TICKETS = __import__("os").environ.get("LCREC_TICKETS", "1") != "0"
+
+
+def _ticket(device):
+    if not USE_TICKETS:
+        return None
+    key = (device.index, _stream_int(device.index))
+    t = _tickets.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.LcrecError("the stream's ticket word must exist before a graph capture (run the step once eagerly first)")
+        t = _tickets[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return t
 
 
 # One lcrec_context per device (include/lcrec.h): the library's helper streams, their events and the pinned upload ring.
@@ -240,12 +259,14 @@ def flatten_codebooks(codebooks):
 
 
 def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=False, xq_init=None, audit=None,
-              tie_tau=None, sse_out=None):
+              tie_tau=None, sse_out=None, idx_into=None):
     """ResidualVectorQuantizer.forward values with use_sk=False (rq.py:39-55).
 
     xq_init: optional [n, e] tensor that the x_q sum starts from (it is updated in place and returned).
     audit: optional dict that receives the near-tie audit outputs (include/lcrec.h): "margin" float32 [n, L] (top-2
     distance gap per level) and, with tie_tau, "neartie" int32 [n] (bit l set = level l is a near tie under tie_tau).
+    idx_into: (matrix, col0) -- write the L index columns straight into columns col0 .. col0+L-1 of a wider contiguous int64
+    [n, L_total] matrix (no copy afterwards); the returned idx is then that column block as a view.
     Returns (idx int64 [n, L], xq [n, e] | None, sse float64 [L] | None, resid [L+1, n, e] | None);
     resid[l] is the residual entering level l, resid[L] the residual left after the last level."""
     lib = _lib.load()
@@ -254,7 +275,15 @@ def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=F
     n, e = z.shape
     L = len(ks)
     dev = z.device
-    idx = torch.empty((n, L), dtype=torch.int64, device=dev)
+    if idx_into is not None:
+        matrix, col0 = idx_into
+        if not (matrix.is_cuda and matrix.dtype == torch.int64 and matrix.dim() == 2 and matrix.is_contiguous()
+                and matrix.shape[0] == n and 0 <= col0 and col0 + L <= matrix.shape[1]):
+            raise _lib.LcrecError("idx_into must be (contiguous int64 [n, L_total] device matrix, first column)")
+        idx, idx_ptr, idx_stride = matrix[:, col0:col0 + L], ctypes.c_void_p(matrix.data_ptr() + 8 * col0), int(matrix.shape[1])
+    else:
+        idx = torch.empty((n, L), dtype=torch.int64, device=dev)
+        idx_ptr, idx_stride = _ptr(idx), L
     if xq_init is not None:
         xq = _dev(xq_init, "xq_init")
         if xq.data_ptr() != xq_init.data_ptr() or tuple(xq.shape) != (n, e):
@@ -268,9 +297,9 @@ def rq_assign(z, codebooks_flat, ks, want_xq=False, want_sse=False, want_resid=F
     with _on(dev):
         nbytes = lib.lcrec_rq_assign_workspace(n, e, karr, L)
         ws = _workspace(nbytes, dev)
-        rc = lib.lcrec_rq_assign(_ptr(z), n, e, _ptr(cb), karr, L, _ptr(idx), _ptr(xq), int(xq_init is not None),
+        rc = lib.lcrec_rq_assign(_ptr(z), n, e, _ptr(cb), karr, L, idx_ptr, idx_stride, _ptr(xq), int(xq_init is not None),
                                  _ptr(sse), _ptr(resid), _ptr(margin), _ptr(neartie), tau, _ptr(ws), ws.numel(),
-                                 _stream_ptr())
+                                 _ptr(_ticket(dev)) if want_sse else None, _stream_ptr())
     _lib.check(rc, "lcrec_rq_assign")
     return idx, xq, sse, resid
 
@@ -347,7 +376,8 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
         nbytes = lib.lcrec_sinkhorn_assign_workspace(n, K, oarr, G)
         ws = _workspace(nbytes, resid.device)
         rc = lib.lcrec_sinkhorn_assign(_ptr(resid), n, e, _ptr(codebook), K, oarr, G, float(epsilon), int(iters),
-                                       _ptr(out), stride, _ptr(ws), ws.numel(), _context(resid.device), _stream_ptr())
+                                       _ptr(out), stride, _ptr(ws), ws.numel(), _context(resid.device),
+                                       _ptr(_ticket(resid.device)), _stream_ptr())
     _lib.check(rc, "lcrec_sinkhorn_assign")
     if G > 0 and int(np.diff(offs).max()) * K > 16384:
         # the one-launch solver for batch-sized problems poisons its output with -1 if its (bounded)
@@ -356,6 +386,10 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
         # so that a training step has no host synchronisation of its own
         # (a single problem: the kernel poisons EVERY row -- whoever timed out set the flag all workgroups read before they
         # write -- so the first row tells; several groups: only the rows of the group that took that path)
+        if _deferred is not None and _deferred_raw and G == 1:
+            # the caller folds the test into a kernel of its own (lcrec_step_losses' poison_probe): hand it the element to look at
+            _deferred.append((_POISON_MSG, out[0:1]))
+            return out
         bad = (out[0] < 0) if G == 1 else (out < 0).any()
         if _deferred is not None:
             _deferred.append(("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "
@@ -367,19 +401,25 @@ def sinkhorn_assign(resid, codebook, epsilon, iters, group_offsets=None, out=Non
 
 
 _deferred = None
+_deferred_raw = False
+_POISON_MSG = ("lcrec_sinkhorn_assign: grid barrier timed out (device oversubscribed?); "
+               "set LCREC_SINKHORN_PERSISTENT=0 to use the multi-launch solver")
 
 
 class deferred_checks:
     """Context in which result checks that need a device->host read (the Sinkhorn poison flag) are
     collected as device booleans and evaluated together at exit, or every `every` collected checks."""
 
-    def __init__(self, every=256):
+    def __init__(self, every=256, raw=False):
+        """raw: single-problem Sinkhorn calls append (message, int64 [1] view of their first assignment) instead of a device
+        boolean -- no compare launch; the caller (engine.py) drains them and tests the element itself (< 0 = poisoned)."""
         self.every = every
+        self.raw = raw
 
     def __enter__(self):
-        global _deferred
-        self._outer = _deferred
-        _deferred = []
+        global _deferred, _deferred_raw
+        self._outer = (_deferred, _deferred_raw)
+        _deferred, _deferred_raw = [], self.raw
         return self
 
     def flush(self):
@@ -403,12 +443,12 @@ class deferred_checks:
         return pending
 
     def __exit__(self, exc_type, exc, tb):
-        global _deferred
+        global _deferred, _deferred_raw
         try:
-            if exc_type is None:
+            if exc_type is None and not self.raw:
                 self.flush()
         finally:
-            _deferred = self._outer
+            _deferred, _deferred_raw = self._outer
         return False
 
 
@@ -445,7 +485,8 @@ def rq_apply_level(resid, codebook, idx, xq=None, want_sse=False, sse_out=None):
     with _on(resid.device):
         ws = _workspace(8192, resid.device)
         rc = lib.lcrec_rq_apply_level(_ptr(resid), n, e, _ptr(codebook), K, _ptr(idx), stride, _ptr(xq),
-                                      int(accumulate), _ptr(nxt), _ptr(sse), _ptr(ws), ws.numel(), _stream_ptr())
+                                      int(accumulate), _ptr(nxt), _ptr(sse), _ptr(ws), ws.numel(),
+                                      _ptr(_ticket(resid.device)) if want_sse else None, _stream_ptr())
     _lib.check(rc, "lcrec_rq_apply_level")
     return xq, nxt, sse
 
@@ -489,8 +530,9 @@ def code_stats_levels(idx, resid_in, ks, codebooks=None, grads_out=None, scale=0
     return list(zip(counts, sums))
 
 
-def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps):
-    """In-place EMA step of index_improve vq.py:155-184 on three contiguous fp32 device tensors."""
+def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps, skip_flag=None):
+    """In-place EMA step of index_improve vq.py:155-184 on three contiguous fp32 device tensors.  skip_flag: a device
+    bool/uint8 scalar; when set the call changes nothing (lcrec_ema_update)."""
     lib = _lib.load()
     for name, t in (("ema_count", ema_count), ("ema_sum", ema_sum), ("codebook", codebook)):
         if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
@@ -501,7 +543,7 @@ def ema_update(ema_count, ema_sum, codebook, count, total, decay, eps):
     keep = 1 - (1 - decay)
     with _on(codebook.device):
         rc = lib.lcrec_ema_update(_ptr(ema_count), _ptr(ema_sum), _ptr(codebook), _ptr(count), _ptr(total), K, e,
-                                  decay, alpha, keep, eps, _stream_ptr())
+                                  decay, alpha, keep, eps, _ptr(skip_flag), _stream_ptr())
     _lib.check(rc, "lcrec_ema_update")
 
 
@@ -724,7 +766,7 @@ def recon_loss_grad(out, x, loss_type="mse", want_grad=True, global_rows=None):
         ws = _workspace(lib.lcrec_train_reduce_workspace(), out.device)
         total = 0 if global_rows is None else int(global_rows) * (out.numel() // max(1, out.shape[0]))
         rc = lib.lcrec_recon_loss_grad(_ptr(out), _ptr(x), out.numel(), total, int(loss_type == "l1"), _ptr(g), _ptr(loss), _ptr(ws),
-                                       ws.numel(), _stream_ptr())
+                                       ws.numel(), _ptr(_ticket(out.device)), _stream_ptr())
     _lib.check(rc, "lcrec_recon_loss_grad")
     return loss, g
 
@@ -736,7 +778,8 @@ def grad_norm_clip(flat_grads, max_norm=1.0, out=None):
     res = out if out is not None else torch.empty(2, dtype=torch.float32, device=g.device)
     with _on(g.device):
         ws = _workspace(lib.lcrec_train_reduce_workspace(), g.device)
-        rc = lib.lcrec_grad_norm_clip(_ptr(g), g.numel(), float(max_norm), _ptr(res), _ptr(ws), ws.numel(), _stream_ptr())
+        rc = lib.lcrec_grad_norm_clip(_ptr(g), g.numel(), float(max_norm), _ptr(res), _ptr(ws), ws.numel(), _ptr(_ticket(g.device)),
+                                      _stream_ptr())
     _lib.check(rc, "lcrec_grad_norm_clip")
     return res
 
@@ -755,15 +798,18 @@ def codebook_grad(count, total, codebook, scale, weight, out):
     return out
 
 
-def step_losses(sse, n, e, beta, quant_loss_weight, recon, losses_out, sums=None, nan_flag=None):
+def step_losses(sse, n, e, beta, quant_loss_weight, recon, losses_out, sums=None, nan_flag=None, poison_probe=None,
+                poison_flag=None):
     """losses_out[3] = (loss, recon, rq_loss) from the per-level sse (float64 [L]) and the reconstruction loss; optional
-    running sums (float64 [2], +=) and NaN flag (bool/uint8 scalar, set) -- lcrec_step_losses."""
+    running sums (float64 [2], +=) and NaN flag (bool/uint8 scalar, set) -- lcrec_step_losses.  poison_probe (int64 [1]
+    device view) / poison_flag (bool/uint8 scalar): the flag is set when the probed assignment is negative."""
     lib = _lib.load()
     if not (sse.is_cuda and sse.dtype == torch.float64 and sse.is_contiguous()):
         raise _lib.LcrecError("sse must be a contiguous float64 device tensor")
     with _on(sse.device):
         rc = lib.lcrec_step_losses(_ptr(sse), sse.numel(), int(n), int(e), float(beta), float(quant_loss_weight), _ptr(recon),
-                                   _ptr(losses_out), _ptr(sums), _ptr(nan_flag), _stream_ptr())
+                                   _ptr(losses_out), _ptr(sums), _ptr(nan_flag), _ptr(poison_probe),
+                                   _ptr(poison_flag) if poison_probe is not None else None, _stream_ptr())
     _lib.check(rc, "lcrec_step_losses")
     return losses_out
 
@@ -783,9 +829,9 @@ def quantizer_input_grad(z, codebook0, idx_col, coef, weight, g_xq):
 
 
 def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=True,
-               clip=None, schedule=-1, warmup_steps=0, total_steps=0, lr_out=None):
+               clip=None, schedule=-1, warmup_steps=0, total_steps=0, lr_out=None, skip_flag=None):
     """One AdamW/Adam step on flat fp32 buffers, all updated in place (see lcrec_adamw_step); `step` is a device int64
-    scalar the call increments."""
+    scalar the call increments.  skip_flag: a device bool/uint8 scalar; when set nothing is updated."""
     lib = _lib.load()
     for name, t in (("params", params), ("grads", grads), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == params.numel()):
@@ -796,7 +842,7 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999),
         rc = lib.lcrec_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), _ptr(clip),
                                   _ptr(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                   int(bool(decoupled)), int(schedule), int(warmup_steps), int(total_steps), _ptr(lr_out),
-                                  _stream_ptr())
+                                  _ptr(_ticket(params.device)), _ptr(skip_flag), _stream_ptr())
     _lib.check(rc, "lcrec_adamw_step")
 
 

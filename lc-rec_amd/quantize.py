@@ -46,9 +46,9 @@ def quantize_values(zc, cbs, beta, plan, want_stats, training, want_code_grads=T
         while m < L and plan[m] is None:
             m += 1
         flat, ks = ops.flatten_codebooks(cbs[l:m])
-        ridx, xq, _, resid = ops.rq_assign(r, flat, ks, want_xq=True, want_sse=True, want_resid=True, xq_init=xq,
-                                           sse_out=sse[l:m])
-        idx[:, l:m] = ridx
+        # (the run's index columns are written in place into the [n, L] matrix: no copy launch afterwards)
+        _, xq, _, resid = ops.rq_assign(r, flat, ks, want_xq=True, want_sse=True, want_resid=True, xq_init=xq,
+                                        sse_out=sse[l:m], idx_into=(idx, l))
         for t in range(l, m):
             resid_in[t] = resid[t - l]
         r = resid[m - l]

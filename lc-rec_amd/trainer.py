@@ -185,8 +185,10 @@ class Trainer(object):
             if reason is None:
                 kind = "linear" if self.lr_scheduler_type.lower() == "linear" else "constant"
                 self.engine = TrainEngine(self.model, self.optimizer, kind, self.warmup_steps, self.max_steps,
-                                          use_ema=self.use_ema, dist=self.dist)
-                self.logger.info("training step: one captured hipGraph per batch size (lcrec_amd.engine)")
+                                          use_ema=self.use_ema, dist=self.dist,
+                                          dp_graph=getattr(self.args, "dp_graph", "auto"))
+                self.logger.info("training step: %s (lcrec_amd.engine)", "one captured hipGraph per batch size"
+                                 if self.engine.use_graph else "the engine's straight line, launched eagerly")
             else:
                 self.logger.info("training step: autograd path (%s)", reason)
         return self.engine
@@ -218,13 +220,19 @@ class Trainer(object):
         self.model.train()
         engine = self._get_engine()
         if engine is not None:
-            iter_data = tqdm(train_data, total=len(train_data), ncols=100, desc=set_color(f"Train {epoch_idx}", "pink"),
-                             disable=not self._is_main())
+            # a device-resident loader hands out (matrix, row indices): the captured step gathers straight into its input
+            selections = getattr(train_data, "iter_selections", None)
+            iter_data = tqdm(selections() if selections else train_data, total=len(train_data), ncols=100,
+                             desc=set_color(f"Train {epoch_idx}", "pink"), disable=not self._is_main())
             engine.begin_epoch()
             for data in iter_data:
-                if self.dist is not None and not self._set_global_batch(train_data, data):
+                rows = data[1] if selections else data
+                if self.dist is not None and not self._set_global_batch(train_data, rows):
                     continue
-                engine.step(data.to(self.device))
+                if selections:
+                    engine.step_selected(data[0], data[1])
+                else:
+                    engine.step(data.to(self.device))
             return engine.end_epoch(self.scheduler)      # raises "Training loss is nan" / solver errors of the epoch
         total_loss = torch.zeros((), dtype=torch.float64, device=self.device)
         total_recon = torch.zeros((), dtype=torch.float64, device=self.device)

@@ -180,7 +180,7 @@ def test_context_pipelines_and_lifetime(hip):
     nbytes = lib.lcrec_sinkhorn_assign_workspace(n, 256, oarr, len(sizes))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = lib.lcrec_sinkhorn_assign(r.data_ptr(), n, 32, cb.data_ptr(), 256, oarr, len(sizes), 0.003, 50, out.data_ptr(), 1,
-                                   ws.data_ptr(), nbytes, None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                   ws.data_ptr(), nbytes, None, None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0 and torch.equal(out, with_ctx)
     h = ctypes.c_void_p()
     assert lib.lcrec_context_create(ctypes.byref(h)) == 0 and h.value

@@ -203,6 +203,79 @@ def test_clip_and_adamw_match_torch(hip, decoupled, schedule):
     np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
 
 
+def test_ticket_forms_give_the_bits_of_the_two_launch_forms(hip):
+    """include/lcrec.h, `ticket` arguments: with the caller's 4-byte word the last workgroup to arrive finishes a partial-sum
+    reduction inside the launch -- same order of additions as the finishing launch it replaces, hence the same bits -- and the
+    word is left zero.  Per-level SSE of lcrec_rq_assign / lcrec_rq_apply_level, the reconstruction loss, the gradient norm,
+    AdamW's step counter, and the Sinkhorn set-up (global min/max by the distance launch's last workgroup)."""
+    ops = hip.ops
+    dev = torch.device(DEV)
+    rs = _rs(31)
+    z = torch.from_numpy(gi.f32(rs.standard_normal((5000, 32)))).to(dev)
+    cbs = [torch.from_numpy(gi.f32(rs.standard_normal((256, 32)) * 0.6 ** l)).to(dev) for l in range(3)]
+    flat, ks = ops.flatten_codebooks(cbs)
+    out = torch.from_numpy(gi.f32(rs.standard_normal((1027, 768)))).to(dev)
+    x = torch.from_numpy(gi.f32(rs.standard_normal((1027, 768)))).to(dev)
+    g = torch.from_numpy(gi.f32(rs.standard_normal(3_000_003) * 0.01)).to(dev)
+    zb = z[:1024].contiguous()
+    res = {}
+    for use in (False, True):
+        ops.USE_TICKETS = use
+        try:
+            idx, xq, sse, resid = ops.rq_assign(z, flat, ks, want_xq=True, want_sse=True, want_resid=True)
+            wide = torch.full((5000, 5), -7, dtype=torch.int64, device=dev)
+            ops.rq_assign(z, flat, ks, want_sse=True, idx_into=(wide, 1))
+            col = ops.sinkhorn_assign(zb, cbs[0], 0.003, 50)
+            _, _, sse1 = ops.rq_apply_level(zb, cbs[0], col, want_sse=True)
+            loss, grad = ops.recon_loss_grad(out, x, "mse")
+            clip = ops.grad_norm_clip(g, 1.0)
+            p = g.clone()
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            step = torch.zeros((), dtype=torch.int64, device=dev)
+            for _ in range(3):
+                ops.adamw_step(p, g.clone(), m, v, step, 1e-3, clip=clip)
+            res[use] = [idx, sse, wide, col, sse1, loss, grad, clip, p, step]
+        finally:
+            ops.USE_TICKETS = True
+    assert int(res[True][9]) == 3 and int(res[False][9]) == 3
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    wide = res[True][2]
+    assert torch.equal(wide[:, 1:4], res[True][0]) and bool((wide[:, 0] == -7).all()) and bool((wide[:, 4] == -7).all())
+    assert int(ops._ticket(dev).abs().sum()) == 0                 # every call left the word zero
+
+
+def test_a_nan_loss_freezes_the_optimizer_and_ema_state(hip):
+    """The sticky NaN flag of lcrec_step_losses as skip_flag of lcrec_adamw_step / lcrec_ema_update: nothing is updated
+    and the step counter stays, i.e. the state a caller finds is that of the last good step -- the effect of the
+    reference raising before the offending step's backward (index/trainer.py:116)."""
+    ops = hip.ops
+    dev = torch.device(DEV)
+    rs = _rs(32)
+    p = torch.from_numpy(gi.f32(rs.standard_normal(10_000))).to(dev)
+    g = torch.from_numpy(gi.f32(rs.standard_normal(10_000))).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros((), dtype=torch.int64, device=dev)
+    flag = torch.zeros(2, dtype=torch.bool, device=dev)
+    sse = torch.tensor([1.0, float("nan")], dtype=torch.float64, device=dev)
+    recon = torch.ones((), dtype=torch.float32, device=dev)
+    last = torch.zeros(3, dtype=torch.float32, device=dev)
+    ops.adamw_step(p, g, m, v, step, 1e-3, skip_flag=flag[0])
+    good = [t.clone() for t in (p, m, v, step)]
+    ops.step_losses(sse, 8, 32, 0.25, 1.0, recon, last, nan_flag=flag[0])
+    assert bool(flag[0]) and not bool(flag[1]) and bool(torch.isnan(last[0]))
+    ops.adamw_step(p, g, m, v, step, 1e-3, skip_flag=flag[0])
+    assert all(torch.equal(a, b) for a, b in zip(good, (p, m, v, step))) and int(step) == 1
+    en, ew = torch.ones(16, device=dev), torch.ones((16, 32), device=dev)
+    cb = torch.ones((16, 32), device=dev)
+    ops.ema_update(en, ew, cb, torch.full((16,), 3.0, device=dev), torch.full((16, 32), 5.0, device=dev), 0.9, 1e-5, skip_flag=flag[0])
+    assert bool((en == 1).all()) and bool((ew == 1).all()) and bool((cb == 1).all())
+    # the poison probe: a negative first assignment sets the second flag
+    probe = torch.tensor([-1], dtype=torch.int64, device=dev)
+    ops.step_losses(sse, 8, 32, 0.25, 1.0, recon, last, nan_flag=flag[0], poison_probe=probe, poison_flag=flag[1])
+    assert bool(flag[1])
+
+
 def _tiny(hip, bn):
     g = np.load(os.path.join(GOLD, f"f4_step_bn{bn}.npz"))
     model = hip.RQVAE(in_dim=128, num_emb_list=[256] * 4, e_dim=16, layers=[64, 32], dropout_prob=0.0, bn=bool(bn),

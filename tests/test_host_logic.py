@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (lcrec_[a-z_0-9]+)", out))
     assert declared <= exported
     lib = lcrec_amd._lib.load()                      # loads without a GPU; nothing is launched
-    assert lib.lcrec_version() == 2 == lcrec_amd._lib.ABI_VERSION
+    assert lib.lcrec_version() == 3 == lcrec_amd._lib.ABI_VERSION
     assert lib.lcrec_last_error() == b""
 
 
@@ -52,13 +52,13 @@ def test_library_argument_errors_are_reported_not_crashed():
     import lcrec_amd
     lib = lcrec_amd._lib.load()
     K = (ctypes.c_int * 1)(256)
-    rc = lib.lcrec_rq_assign(None, 10, 32, None, K, 1, None, None, 0, None, None, None, None, 0.0, None, 0, None)
+    rc = lib.lcrec_rq_assign(None, 10, 32, None, K, 1, None, 0, None, 0, None, None, None, None, 0.0, None, 0, None, None)
     assert rc == -1 and b"NULL" in lib.lcrec_last_error()
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    rc = lib.lcrec_rq_assign(p, 1, 24, p, K, 1, p, None, 0, None, None, None, None, 0.0, None, 0, None)
+    rc = lib.lcrec_rq_assign(p, 1, 24, p, K, 1, p, 0, None, 0, None, None, None, None, 0.0, None, 0, None, None)
     assert rc == -2 and b"e_dim=24" in lib.lcrec_last_error()
-    rc = lib.lcrec_rq_assign(p, 1, 32, p, K, 1, p, None, 0, None, None, None, p, -1.0, None, 0, None)
+    rc = lib.lcrec_rq_assign(p, 1, 32, p, K, 1, p, 0, None, 0, None, None, None, p, -1.0, None, 0, None, None)
     assert rc == -1 and b"tie_tau" in lib.lcrec_last_error()
     # the context API's argument checks (no device needed: nothing is created before first use)
     assert lib.lcrec_context_create(None) == -1
