@@ -134,6 +134,30 @@ __device__ __forceinline__ bool ticket_is_last(unsigned *ticket, unsigned workgr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return true;
 }
+// Sum of `count` handed-over partials (element b at base[b * stride]) in index order, by ONE wave: the lanes fetch them side by
+// side (a chain of dependent agent-scope loads would cost a memory round trip each), the additions then run in order over
+// shuffled-in values -- ((p0 + p1) + p2) + ..., the bits of a sequential loop.  count <= 64 * HANDOFF_MAX_PER_LANE; every lane
+// of the wave must call it; the sum is returned in every lane.
+constexpr int HANDOFF_MAX_PER_LANE = 4;
+constexpr int TICKET_MAX_WORKGROUPS = 64 * HANDOFF_MAX_PER_LANE;   // also keeps same-address ticket adds cheap (~5 ns each, serialised)
+__device__ __forceinline__ double handoff_sum_ordered(const double *base, int count, int stride)
+{
+    const int lane = threadIdx.x & 63;
+    double x[HANDOFF_MAX_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < HANDOFF_MAX_PER_LANE; ++j) {
+        const int b = lane + 64 * j;
+        x[j] = b < count ? handoff_get(base + (size_t)b * stride) : 0.0;
+    }
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < HANDOFF_MAX_PER_LANE; ++j) {
+        if (64 * j >= count) break;
+        const int m = count - 64 * j < 64 ? count - 64 * j : 64;
+        for (int b = 0; b < m; ++b) v += __shfl(x[j], b, 64);
+    }
+    return v;
+}
 #endif
 
 // LCREC_OK when ctx is NULL or belongs to the current device

@@ -353,20 +353,22 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
             }
             return;
         }
-        // ticket form: thread 0 publishes all of the workgroup's level sums (L <= 16), takes the ticket, and in the last
-        // workgroup to arrive adds every workgroup's partials in workgroup order -- rq_sse_finalize_kernel's sums, its bits
+        // ticket form: thread 0 publishes all of the workgroup's level sums (L <= 16) and takes the ticket; in the last workgroup
+        // to arrive wave 0 adds every workgroup's partials in workgroup order -- rq_sse_finalize_kernel's sums, its bits
+        __shared__ int last_sh;
         if (tid == 0) {
             for (int l = p.l0; l < p.l1; ++l) {
                 double v = 0.0;
                 for (int w = 0; w < WAVES; ++w) v += wave_sse[w * p.L + l];
                 handoff_put(p.sse_partial + (size_t)blockIdx.x * p.L + l, v);
             }
-            if (ticket_is_last(p.ticket, gridDim.x)) {
-                for (int l = p.l0; l < p.l1; ++l) {
-                    double v = 0.0;
-                    for (unsigned b = 0; b < gridDim.x; ++b) v += handoff_get(p.sse_partial + (size_t)b * p.L + l);
-                    p.sse_out[l] = v;
-                }
+            last_sh = ticket_is_last(p.ticket, gridDim.x) ? 1 : 0;
+        }
+        __syncthreads();
+        if (last_sh && tid < 64) {
+            for (int l = p.l0; l < p.l1; ++l) {
+                const double v = handoff_sum_ordered(p.sse_partial + l, (int)gridDim.x, p.L);
+                if (tid == 0) p.sse_out[l] = v;
             }
         }
     }

@@ -383,8 +383,10 @@ __global__ __launch_bounds__(CR_THREADS) void relu_bias_backward_kernel(const fl
 }
 
 // ---- whole-tensor reductions: per-workgroup fp64 partials, then one finishing workgroup (fixed order)
-constexpr int RED_THREADS = 256;
-constexpr int RED_MAX_BLOCKS = 1024;
+// 1024-thread workgroups, at most 256 of them: as many loads in flight as 1024 x 256 threads, a quarter of the partials -- and
+// of the ticket adds, which serialise on their one address (measured: 1024 arrivals cost the gradient-norm launch 8 us)
+constexpr int RED_THREADS = 1024;
+constexpr int RED_MAX_BLOCKS = TICKET_MAX_WORKGROUPS;
 
 __device__ __forceinline__ double block_sum(double v, double *sm)
 {
@@ -540,7 +542,8 @@ __device__ __forceinline__ double lr_at(const AdamParams &a, int64_t s)
 // torch.optim.AdamW / Adam, single-tensor formulation (the fused kernel's arithmetic: state in fp32, hyper-parameters in
 // double), on the flat parameter buffer, with the clip coefficient applied to the gradient on the way in (and stored back,
 // as clip_grad_norm_ leaves it).
-__global__ __launch_bounds__(256) void adamw_step_kernel(AdamParams a)
+constexpr int ADAM_THREADS = 1024;
+__global__ __launch_bounds__(ADAM_THREADS) void adamw_step_kernel(AdamParams a)
 {
     const bool skip = a.skip && *a.skip;              // uniform over the launch
     const int64_t s = *a.step;                       // steps taken before this one
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(AdamParams a)
     const float epsf = (float)a.eps, bc2s = (float)bc2_sqrt;
     const float decay = (float)(lr * a.weight_decay), wd = (float)a.weight_decay;
     if (!skip) {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * 256) {
+        for (int64_t i = (int64_t)blockIdx.x * ADAM_THREADS + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * ADAM_THREADS) {
             float p = a.p[i], g = a.g[i] * coef, m = a.m[i], v = a.v[i];
             a.g[i] = g;
             if (a.weight_decay != 0.0) {
@@ -839,10 +842,10 @@ int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const floa
     if (schedule < -1 || schedule > 1) return fail(LCREC_EINVAL, "adamw_step: schedule %d (supported: -1 none, 0 constant, 1 linear)", schedule);
     AdamParams a = {p, g, m, v, count, clip, step, base_lr, beta1, beta2, eps, weight_decay, decoupled, schedule, warmup_steps,
                     total_steps, lr_out, ticket, skip};
-    int64_t blocks = (count + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = (count + ADAM_THREADS * 8 - 1) / (ADAM_THREADS * 8);
+    if (blocks > TICKET_MAX_WORKGROUPS) blocks = TICKET_MAX_WORKGROUPS;
     TraceScope trace(K_ADAMW, stream);
-    hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)blocks), dim3(ADAM_THREADS), 0, stream, a);
     if (!ticket) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, stream, step, skip);
     return check_launch("adamw_step_kernel");
 }

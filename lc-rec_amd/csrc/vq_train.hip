@@ -51,7 +51,7 @@ __device__ __forceinline__ float ord2f(unsigned u)
 
 constexpr int DIST_ITEMS = 32;   // items per block in the distance kernel
 
-constexpr int DIST_TICKET_MAX_BLOCKS = 4096;    // (min, max) partials of the ticket form: 8 bytes per workgroup
+constexpr int DIST_TICKET_MAX_BLOCKS = 4096;   // (a batch of 1024 rows at K = 256: 32 workgroups)    // (min, max) partials of the ticket form: 8 bytes per workgroup
 
 // grid = (ceil(n/DIST_ITEMS), ceil(K/256)); d is [n][K]; minmax = {ord(min), ord(max)}: initialised by an earlier launch and
 // reached by atomics -- or, with a ticket (include/lcrec.h), written by the last workgroup to arrive from every workgroup's
@@ -110,21 +110,32 @@ __global__ __launch_bounds__(256) void vq_distance_kernel(const float *__restric
         if (ticket) {
             const unsigned nblk = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
             for (int64_t i = (int64_t)me * 256 + tid; i < slot_count; i += (int64_t)nblk * 256) slots[i] = ~0ull;   // SKP_EMPTY
+            __shared__ int last_sh;
             if (tid == 0) {
                 unsigned a = red[0][0], b = red[1][0];
                 for (int w = 1; w < 4; ++w) { a = red[0][w] < a ? red[0][w] : a; b = red[1][w] > b ? red[1][w] : b; }
                 __hip_atomic_store(mm_partial + 2 * me, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(mm_partial + 2 * me + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ticket_is_last(ticket, nblk)) {
-                    for (unsigned q = 0; q < nblk; ++q) {
-                        const unsigned a2 = __hip_atomic_load(mm_partial + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned b2 = __hip_atomic_load(mm_partial + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a = a2 < a ? a2 : a;
-                        b = b2 > b ? b2 : b;
-                    }
-                    minmax[0] = a; minmax[1] = b;
-                    for (int w = 2; w < 8; ++w) minmax[w] = 0u;          // barrier counter, timeout flag
+                last_sh = ticket_is_last(ticket, nblk) ? 1 : 0;
+            }
+            __syncthreads();
+            if (last_sh && tid < 64) {
+                // the lanes of wave 0 fetch the partials side by side (min / max: any order gives the same result)
+                unsigned a = 0xffffffffu, b = 0u;
+                for (unsigned q = tid; q < nblk; q += 64) {
+                    const unsigned a2 = __hip_atomic_load(mm_partial + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned b2 = __hip_atomic_load(mm_partial + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a = a2 < a ? a2 : a;
+                    b = b2 > b ? b2 : b;
                 }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned a2 = __shfl_xor(a, o, 64), b2 = __shfl_xor(b, o, 64);
+                    a = a2 < a ? a2 : a;
+                    b = b2 > b ? b2 : b;
+                }
+                if (tid == 0) { minmax[0] = a; minmax[1] = b; }
+                if (tid >= 2 && tid < 8) minmax[tid] = 0u;            // barrier counter, timeout flag
             }
             return;
         }
@@ -517,18 +528,22 @@ __global__ __launch_bounds__(256) void apply_level_kernel(const float *__restric
         part = wave_sum(part);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
         __syncthreads();
+        __shared__ int last_sh;
         if (threadIdx.x == 0) {
             const double mine = wsum[0] + wsum[1] + wsum[2] + wsum[3];
             if (!ticket) {
                 sse_partial[blockIdx.x] = mine;
             } else {
-                // (include/lcrec.h, `ticket`) the last workgroup to arrive adds the partials, in sum_partials_kernel's order
                 handoff_put(sse_partial + blockIdx.x, mine);
-                if (ticket_is_last(ticket, gridDim.x)) {
-                    double s = 0.0;
-                    for (unsigned b = 0; b < gridDim.x; ++b) s += handoff_get(sse_partial + b);
-                    *sse_out = s;
-                }
+                last_sh = ticket_is_last(ticket, gridDim.x) ? 1 : 0;
+            }
+        }
+        if (ticket) {
+            // (include/lcrec.h, `ticket`) the last workgroup to arrive adds the partials, in sum_partials_kernel's order
+            __syncthreads();
+            if (last_sh && threadIdx.x < 64) {
+                const double s = handoff_sum_ordered(sse_partial, (int)gridDim.x, 1);
+                if (threadIdx.x == 0) *sse_out = s;
             }
         }
     }
@@ -1559,6 +1574,7 @@ int apply_level(const float *r_in, int64_t n, int e, const float *cb, int K, con
     if (n == 0) return LCREC_OK;
     int64_t blocks = (n * (e / 4) + 255) / 256;
     if (blocks > 1024) blocks = 1024;
+    if (sse_out && blocks > TICKET_MAX_WORKGROUPS) blocks = TICKET_MAX_WORKGROUPS;   // (both forms: the sum's grouping follows the grid)
     double *partial = nullptr;
     if (sse_out) {
         if (!workspace || workspace_bytes < 1024 * sizeof(double))

@@ -92,6 +92,8 @@ class TrainEngine:
         self.last_idx = None
         self._bn_counters = None                                             # BatchNorm1d.num_batches_tracked tensors ...
         self._bn_pending = 0                                                 # ... and the steps not yet added to them
+        # whoever reads the state dict (a checkpoint, a test) sees the host-side bookkeeping brought up to date first
+        model.register_state_dict_pre_hook(lambda _m, _prefix, _keep: self.sync_host_state())
 
     # ------------------------------------------------------------------ support matrix
     @staticmethod
@@ -347,6 +349,8 @@ class TrainEngine:
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            ops._ticket(self.device)                     # the capture stream's ticket word (zeroed here, outside the capture)
         # Data parallel: the process group's watchdog THREAD polls the events of collectives issued before the capture
         # (hipEventQuery); in the default "global" capture mode such a call from any thread is an error that invalidates the
         # capture -- and kills the watchdog, which takes the process down (seen once in ~10 runs).  "thread_local" confines the
