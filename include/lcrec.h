@@ -100,6 +100,29 @@ int lcrec_linear_forward(const float *x, int64_t n, int in_dim, const float *W, 
                          const float *bn_scale, const float *bn_shift, int relu, int out_dim,
                          float *y, void *stream);
 
+/* One Linear of a TRAINING step with the BatchNorms on either side of it folded in (index/models/layers.py:23-30 in train();
+ * the reference runs Linear, BatchNorm1d and ReLU as three modules with a full activation tensor between each pair):
+ *   u = x * in_scale + in_shift, clamped at 0 from below when in_relu != 0   (in_scale / in_shift [in_dim], both NULL: u = x)
+ *         -- the PREVIOUS layer's BatchNorm + ReLU, applied while the operand tile is staged: that layer's activation
+ *            is never written, its pre-BatchNorm output is all that exists;
+ *   t_out [n][out_dim] = u @ W^T + b   (the same fp32 fma chains as lcrec_linear_forward, bit for bit, on u);
+ *   want_stats != 0: the batch statistics of t_out over its n rows -- THIS layer's BatchNorm (layers.py:26) -- taken in the
+ *         product's epilogue: mean_out, rstd_out = 1/sqrt(biased var + eps), scale_out = gamma * rstd, shift_out = beta -
+ *         mean * scale_out (what the next lcrec_linear_bn_forward takes as in_scale / in_shift), and running_mean /
+ *         running_var (may be NULL) updated with `momentum` as nn.BatchNorm1d does (unbiased variance).  gamma / beta may
+ *         be NULL (1 / 0).  Every tile publishes per-column partial sums; the last tile of a column strip to arrive merges
+ *         them in tile order (deterministic; see "ticket arguments"): tickets = ceil(out_dim / 64) zeroed words, left zero.
+ *   workspace: lcrec_linear_bn_forward_workspace(n, out_dim) bytes (want_stats only).
+ * Batch-sized launches only (n <= a few thousand rows: the tile rule of a training step), in_dim % 32 == 0, out_dim % 4 == 0,
+ * out_dim <= 4096; anything else returns LCREC_EUNSUPPORTED and the caller uses lcrec_linear_forward + lcrec_bn_relu_forward.
+ * Statistics agree with torch's to ~1e-7 relative (another summation order); pinned by fixtures F4 and F11 through the engine. */
+size_t lcrec_linear_bn_forward_workspace(int64_t n, int out_dim);
+int lcrec_linear_bn_forward(const float *x, int64_t n, int in_dim, const float *in_scale, const float *in_shift, int in_relu,
+                            const float *W, const float *b, int out_dim, float *t_out, int want_stats, const float *gamma,
+                            const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                            float *mean_out, float *rstd_out, float *scale_out, float *shift_out, void *workspace,
+                            size_t workspace_bytes, unsigned int *tickets, void *stream);
+
 /* The two backward products of one Linear layer, as autograd derives them for nn.Linear in
  * MLPLayers (index/models/layers.py:23; driven by loss.backward() at index/trainer.py:117,
  * SURVEY.md row a9):
@@ -132,6 +155,11 @@ typedef struct {
     float *gw;         /* [out_dim][in_dim] */
     int64_t n;
     int in_dim, out_dim;
+    /* ABI 3: both NULL, or [in_dim] device vectors: the layer's input is then u = x * x_scale + x_shift, clamped at 0 from
+     * below when x_relu != 0 -- x being the PRE-BatchNorm output of the previous layer as lcrec_linear_bn_forward leaves it
+     * and (x_scale, x_shift) that BatchNorm's folded affine; u is formed on the operand's way into LDS. */
+    const float *x_scale, *x_shift;
+    int x_relu;
 } lcrec_dw_problem;
 size_t lcrec_linear_backward_weights_workspace(const lcrec_dw_problem *problems, int count);
 int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, int count, void *workspace, size_t workspace_bytes,
@@ -297,10 +325,12 @@ int lcrec_bn_relu_forward(const float *t, int64_t n, int features, const float *
 /* Backward of the above for gy = dL/dy (what autograd derives for layers.py:25-30 under loss.backward(),
  * index/trainer.py:117):  g = gy * [y > 0];  dbeta = sum g;  dgamma = sum g*xhat;
  * dt = gamma*rstd*(g - dbeta/n - xhat*dgamma/n);  dbias = sum dt -- the gradient of the Linear bias feeding the
- * BatchNorm (zero up to rounding, as in the reference).  dgamma/dbeta/dbias may be NULL; dt may alias gy. */
+ * BatchNorm (zero up to rounding, as in the reference).  dgamma/dbeta/dbias may be NULL; dt may alias gy.
+ * y may be NULL when relu != 0 and fold_scale / fold_shift [features] are given: the mask is then [t * fold_scale +
+ * fold_shift > 0] (one fma), the expression the consumer of lcrec_linear_bn_forward's output evaluated. */
 int lcrec_bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
                            const float *mean, const float *rstd, int relu, float *dt_out, float *dgamma_out,
-                           float *dbeta_out, float *dbias_out, void *stream);
+                           float *dbeta_out, float *dbias_out, const float *fold_scale, const float *fold_shift, void *stream);
 
 /* The same two operations split where an item-sharded (data-parallel) run exchanges statistics, so that the batch is the
  * union of all ranks' rows (torch.nn.SyncBatchNorm semantics; the reference's index/ stage is single-process, SURVEY.md

@@ -63,7 +63,11 @@ _SIGNATURES = {
     "lcrec_bn_relu_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp,
                                              _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
     "lcrec_bn_relu_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _vp,
-                                              _vp, _vp, _vp, _vp]),
+                                              _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lcrec_linear_bn_forward_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
+    "lcrec_linear_bn_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp,
+                                               ctypes.c_int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               _vp, ctypes.c_size_t, _vp, _vp]),
     "lcrec_bn_stats": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp]),
     "lcrec_bn_relu_apply": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
     "lcrec_bn_backward_reduce": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp,
@@ -97,7 +101,8 @@ _SIGNATURES = {
 class DwProblem(ctypes.Structure):
     """lcrec_dw_problem of include/lcrec.h"""
     _fields_ = [("gy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("gw", ctypes.c_void_p), ("n", ctypes.c_int64),
-                ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int)]
+                ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("x_scale", ctypes.c_void_p), ("x_shift", ctypes.c_void_p),
+                ("x_relu", ctypes.c_int)]
 
 
 class TraceEntry(ctypes.Structure):

@@ -379,10 +379,24 @@ LCREC_API int lcrec_bn_relu_forward(const float *t, int64_t n, int features, con
 
 LCREC_API int lcrec_bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
                                      const float *mean, const float *rstd, int relu, float *dt_out, float *dgamma_out,
-                                     float *dbeta_out, float *dbias_out, void *stream)
+                                     float *dbeta_out, float *dbias_out, const float *fold_scale, const float *fold_shift,
+                                     void *stream)
 {
-    return bn_relu_backward(gy, t, y, n, features, gamma, mean, rstd, relu, dt_out, dgamma_out, dbeta_out, dbias_out,
-                            (hipStream_t)stream);
+    return bn_relu_backward(gy, t, y, n, features, gamma, mean, rstd, relu, dt_out, dgamma_out, dbeta_out, dbias_out, fold_scale,
+                            fold_shift, (hipStream_t)stream);
+}
+
+LCREC_API size_t lcrec_linear_bn_forward_workspace(int64_t n, int out_dim) { return linear_bn_forward_workspace(n, out_dim); }
+
+LCREC_API int lcrec_linear_bn_forward(const float *x, int64_t n, int in_dim, const float *in_scale, const float *in_shift, int in_relu,
+                                      const float *W, const float *b, int out_dim, float *t_out, int want_stats, const float *gamma,
+                                      const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                      float *mean_out, float *rstd_out, float *scale_out, float *shift_out, void *workspace,
+                                      size_t workspace_bytes, unsigned int *tickets, void *stream)
+{
+    return linear_bn_forward(x, n, in_dim, in_scale, in_shift, in_relu, W, b, out_dim, t_out, want_stats, gamma, beta, eps, momentum,
+                             running_mean, running_var, mean_out, rstd_out, scale_out, shift_out, workspace, workspace_bytes, tickets,
+                             (hipStream_t)stream);
 }
 
 LCREC_API int lcrec_relu_bias_backward(const float *gy, const float *y, int64_t n, int features, int relu, float *g_out,

@@ -168,6 +168,13 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
                    const float *bn_scale, const float *bn_shift, int relu, int out_dim, float *y,
                    hipStream_t stream);
 
+size_t linear_bn_forward_workspace(int64_t n, int out_dim);
+int linear_bn_forward(const float *x, int64_t n, int in_dim, const float *in_scale, const float *in_shift, int in_relu,
+                      const float *W, const float *b, int out_dim, float *t_out, int want_stats, const float *gamma,
+                      const float *beta, float eps, float momentum, float *running_mean, float *running_var, float *mean_out,
+                      float *rstd_out, float *scale_out, float *shift_out, void *workspace, size_t workspace_bytes,
+                      unsigned *tickets, hipStream_t stream);
+
 int linear_backward_splits(int64_t n, int in_dim, int out_dim);
 size_t linear_backward_workspace(int64_t n, int in_dim, int out_dim);
 int linear_backward(const float *gy, const float *x, const float *W, int64_t n, int in_dim, int out_dim, float *gx, float *gw,
@@ -204,7 +211,8 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
                     float *running_mean, float *running_var, float *y, float *mean_out, float *rstd_out, int relu,
                     hipStream_t stream);
 int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
-                     const float *rstd, int relu, float *dt, float *dgamma, float *dbeta, float *dbias, hipStream_t stream);
+                     const float *rstd, int relu, float *dt, float *dgamma, float *dbeta, float *dbias, const float *fold_scale,
+                     const float *fold_shift, hipStream_t stream);
 int bn_stats(const float *t, int64_t n, int F, float *mean_out, float *m2_out, hipStream_t stream);
 int bn_merge_stats(const float *rows, int world, int F, float eps, float momentum, float *mean_out, float *rstd_out,
                    float *running_mean, float *running_var, hipStream_t stream);

@@ -224,6 +224,27 @@ __device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t r, int
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// What a TRAINING step adds to a tile (lcrec_linear_bn_forward, lcrec_linear_backward_weights with input transforms):
+//   PRO = 1  the row-major A operand is u = max(a * in_scale[k] + in_shift[k], in_lo) on its way into LDS -- the BatchNorm
+//            affine + ReLU of the layer that produced `a`, which therefore never has to be written out (layers.py:25-30);
+//   PRO = 2  the same for the k-major "W" operand of dW = dY^T X (X is the layer input; scale / shift run along its
+//            columns), rows past the batch kept zero;
+//   STATS    per-column batch statistics of the output t = acc + bias in the epilogue: every tile publishes, per column,
+//            (pivot, sum (t - pivot), sum (t - pivot)^2) over its valid rows (pivot = the tile's first row: a sample of the
+//            column, so the sums lose a bit or two, not the digits E[t^2] - mean^2 loses); the LAST tile of a column strip to
+//            arrive (ticket per strip, include/lcrec.h) merges the row tiles' records in tile order (Chan et al.) and
+//            writes mean, rstd, the folded scale / shift of this BatchNorm and its running statistics.
+struct TileExtras {
+    const float *in_scale, *in_shift;   // PRO: [K] (PRO 1) or [N] (PRO 2)
+    float in_lo;                        // 0 (ReLU) or -inf
+    float *stat_partial;                // STATS: [bm_blocks][3][N]
+    unsigned *tickets;                  // STATS: [bn_blocks], zero before and after
+    const float *gamma, *beta;          // STATS: [N] (NULL = 1 / 0)
+    float eps, momentum;
+    float *running_mean, *running_var;  // STATS: updated in place, or NULL
+    float *mean_out, *rstd_out, *scale_out, *shift_out;   // STATS: [N]
+};
+
 // TA / TB: the A / W operand is given K-MAJOR ([K][M] resp. [K][N] row-major) instead of [M][K] / [N][K].  These are
 // the operand shapes of the two backward products of a Linear layer -- dX = dY W reads W [out][in] as the
 // k-major "W" of an [n][in] output, dW = dY^T X reads dY [n][out] and X [n][in] both k-major -- so no transposed
@@ -231,14 +252,15 @@ __device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t r, int
 // rows of a 16-byte global load); chain order over k is unchanged.  Requires FAST.
 // The tile body; `bid` / `split` are the workgroup's tile number and K-run (blockIdx.x / blockIdx.y of a plain launch, or
 // what a grouped launch derives from its problem table).
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, bool TB = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, bool TB = false, int PRO = 0, bool STATS = false>
 __device__ __forceinline__ void linear_tile_body(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ C,
     int64_t M, int N, int K, int relu, int bn_blocks, int bm_blocks, int tune, int kt_per_split, int64_t split_stride,
-    unsigned bid, unsigned split)
+    unsigned bid, unsigned split, const TileExtras &ex = TileExtras{})
 {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static_assert(PRO == 0 || (PRO == 1 && !TA) || (PRO == 2 && TB), "PRO 1: row-major A; PRO 2: k-major W");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     // one allocation: the epilogue stages 4 x 32 output rows from its start, which is more than As when BM = 64
     static_assert(BM + BN >= 128, "the epilogue needs 128 staging rows");
@@ -249,6 +271,7 @@ __device__ __forceinline__ void linear_tile_body(
     // -> 49 (prefetch distance 2, second LDS buffer) -> 38.7 (this form; the MFMA pipe alone needs 27.3): what the in-kernel
     // stamps (tools/rb_stamp_probe.py) and leave-one-out builds showed on the way is noted at each piece.
     constexpr bool DB = FAST && (TM * TN == 1 || (TM * TN == 2 && WAVES_M == 2));
+    static_assert((PRO == 0 && !STATS) || DB, "the training-step extras live in the register-buffered K-tile");
     constexpr int BUF = (BM + BN) * LDK;
     __shared__ __attribute__((aligned(16))) float smem[BUF * (DB ? 2 : 1)];
     float *const As = smem, *const Ws = smem + BM * LDK;
@@ -450,6 +473,31 @@ __device__ __forceinline__ void linear_tile_body(
     // cycles per K-tile against the MFMA pipe's 1 024.)  Stores and loads are unconditional (a K-tile past the end is
     // zeros from an out-of-range load; nobody multiplies it), so there is no branch for the waitcnt bookkeeping to merge.
     struct Frag { f32x4 a[TM][4], w[TN][4]; };
+    // PRO 1: scale / shift of the K-tile whose A rows go to LDS in the NEXT iteration, per half of the thread's 32-byte share
+    // (k = 32 kt + 16 half + 4 (tid & 3) ..+3: the same for all of the thread's rows); two sets, alternating with the K-tile
+    struct ProRegs { f32x4 s[2], h[2]; };
+    ProRegs pro[2];
+    const __amdgpu_buffer_rsrc_t ps_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ex.in_scale), 0, PRO == 1 ? K * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ph_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ex.in_shift), 0, PRO == 1 ? K * 4 : 0, 0x00020000);
+    auto pro_load = [&](ProRegs &q, int kt, auto half_c) {
+        constexpr int half = decltype(half_c)::value;
+        if constexpr (PRO == 1) {
+            const int vo = (tid & 3) * 16 + half * 64;
+            q.s[half] = buffer_load_f32x4(ps_rsrc, vo, kt * (BK * 4));        // (past K: zeros -- u = max(0, lo), never multiplied)
+            q.h[half] = buffer_load_f32x4(ph_rsrc, vo, kt * (BK * 4));
+        }
+    };
+    // PRO 2: the thread's four columns of the k-major operand never change: scale / shift once, in registers
+    f32x4 pcs = {1.f, 1.f, 1.f, 1.f}, pch = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PRO == 2) {
+        constexpr int Q = BN / 4;
+        const int r4 = tid % Q;
+        if (ex.in_scale && n0 + r4 * 4 < N) {
+            pcs = *reinterpret_cast<const f32x4 *>(ex.in_scale + n0 + r4 * 4);
+            pch = *reinterpret_cast<const f32x4 *>(ex.in_shift + n0 + r4 * 4);
+        }
+    }
+    const float pro_lo = ex.in_lo;
     // A K-MAJOR operand (TA / TB: the backward products) keeps its LDS image k-major too in this form: [32 k][ROWS], no
     // padding.  Its global loads are 16 bytes = four rows of one k, so a K-tile goes to LDS with one conflict-free
     // ds_write_b128 per load (row-major image: four rows 36 floats apart per load, 16 r4 + 4 i + slot mod 32 -- the 32 lanes
@@ -480,17 +528,29 @@ __device__ __forceinline__ void linear_tile_body(
         }
     };
     // quarter `piece` of a K-tile's LDS stores: operand A (0, 1) or W (2, 3), first or second half of the thread's share
-    auto store_piece = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_, int buf, auto piece_c) {
+    auto store_piece = [&](const StageRegs<BM> &ra_, const StageRegs<BN> &rw_, int buf, auto piece_c, int kt_s = 0,
+                           const ProRegs *q = nullptr) {
         constexpr int piece = decltype(piece_c)::value, half = piece & 1;
-        auto one = [&](const auto &r, float *lds, auto rows_c, auto kmajor_c) {
+        auto one = [&](const auto &r, float *lds, auto rows_c, auto kmajor_c, auto pro_c) {
             constexpr int ROWS = decltype(rows_c)::value;
+            constexpr int pro_kind = decltype(pro_c)::value;
             if constexpr (decltype(kmajor_c)::value) {
                 constexpr int Q = ROWS / 4, KSTEP = 256 / Q, NL = ROWS / 32;      // (Q * 32 >= 256: every thread has a share)
                 const int kk = tid / Q, r4 = tid % Q;
                 const uint32_t addr = lds_addr(lds) + (uint32_t)((kk * ROWS + r4 * 4) * 4);
 #pragma unroll
                 for (int j = half; j < NL; j += 2) {
-                    const f32x4 v = r.v[j >> 1][j & 1];
+                    f32x4 v = r.v[j >> 1][j & 1];
+                    if constexpr (pro_kind == 2) {
+                        // this load's k (a batch row) is kt_s * 32 + j * KSTEP + kk; rows past the batch stay zero
+                        const bool in_batch = kt_s * BK + j * KSTEP + kk < K;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float u = __builtin_fmaf(v[t], pcs[t], pch[t]);
+                            u = u > pro_lo ? u : pro_lo;
+                            v[t] = in_batch ? u : 0.f;
+                        }
+                    }
                     asm volatile("ds_write_b128 %0, %1" ::"v"(addr + (uint32_t)(j * KSTEP * ROWS * 4)), "v"(v) : "memory");
                 }
             } else {
@@ -503,14 +563,21 @@ __device__ __forceinline__ void linear_tile_body(
                         // store half spread two-deep over 16 banks, which a ds_write2_b32's transfer time covers: no conflicts,
                         // no v_mov (the first form's four ds_write2_b32 per eight floats landed on 8 banks each: 4x)
                         const uint32_t a = lds_addr(lds) + t_w + (uint32_t)((it * 64 * LDK + half * 16) * 4);
-                        const f32x4 v = r.v[it][half];
+                        f32x4 v = r.v[it][half];
+                        if constexpr (pro_kind == 1) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const float u = __builtin_fmaf(v[t], q->s[half][t], q->h[half][t]);
+                                v[t] = u > pro_lo ? u : pro_lo;
+                            }
+                        }
                         asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(a), "v"(v[0]), "v"(v[2]) : "memory");
                         asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" ::"v"(a), "v"(v[1]), "v"(v[3]) : "memory");
                     }
             }
         };
-        if constexpr (piece < 2) one(ra_, As + buf * BUF, IntC<BM>{}, IntC<TA ? 1 : 0>{});
-        else one(rw_, Ws + buf * BUF, IntC<BN>{}, IntC<TB ? 1 : 0>{});
+        if constexpr (piece < 2) one(ra_, As + buf * BUF, IntC<BM>{}, IntC<TA ? 1 : 0>{}, IntC<PRO == 1 ? 1 : 0>{});
+        else one(rw_, Ws + buf * BUF, IntC<BN>{}, IntC<TB ? 1 : 0>{}, IntC<PRO == 2 ? 2 : 0>{});
     };
     // quarter `piece` of a K-tile's global loads, split like the stores: operand A (0, 1) or W (2, 3), first or second 16 bytes
     // of each of the thread's 32-byte shares.  Issued one per MFMA gap: at the top of the iteration the four waves' sixteen
@@ -563,7 +630,10 @@ __device__ __forceinline__ void linear_tile_body(
             // Leaving out, one at a time, the reads / the barrier / the loads (wrong results, timing only): 36.9 / 38.3 / 36.1.
             if constexpr (s < NREAD) frag_read(fn, IntC<s>{}, cur ^ 1);
             if constexpr (s < 4) load_piece(ra_free, rw_free, kt + LCREC_GEMM_RING + 1, live, IntC<s>{});
-            if constexpr (s >= 5 && s <= 11 && (s & 1) == 1) store_piece(ra_next, rw_next, cur, IntC<(s - 5) / 2>{});
+            // (PRO 1) scale / shift of K-tile kt+3, whose A rows iteration kt+1 stores: two 16-byte loads in each of gaps 12 and 13,
+            // half an iteration ahead of their use, into the set the previous iteration's stores have finished with
+            if constexpr (PRO == 1 && (s == 12 || s == 13)) pro_load(pro[cur ^ 1], kt + 3, IntC<s - 12>{});
+            if constexpr (s >= 5 && s <= 11 && (s & 1) == 1) store_piece(ra_next, rw_next, cur, IntC<(s - 5) / 2>{}, kt + 2, &pro[cur]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (s == 7) LCREC_GSTAMP(2);
         });
@@ -591,8 +661,15 @@ __device__ __forceinline__ void linear_tile_body(
                 constexpr int j = decltype(j_c)::value + 2;
                 static_for<4>([&](auto p_c) { load_piece(sa[j], sw[j], kt0 + j, kt0 + j < nk, p_c); });
             });
-            static_for<4>([&](auto p_c) { store_piece(sa[0], sw[0], 0, p_c); });
-            static_for<4>([&](auto p_c) { store_piece(sa[1], sw[1], 1, p_c); });
+            if constexpr (PRO == 1) {
+                static_for<2>([&](auto h_c) { pro_load(pro[0], kt0, h_c); pro_load(pro[1], kt0 + 1, h_c); });
+            }
+            static_for<4>([&](auto p_c) { store_piece(sa[0], sw[0], 0, p_c, kt0, &pro[0]); });
+            static_for<4>([&](auto p_c) { store_piece(sa[1], sw[1], 1, p_c, kt0 + 1, &pro[1]); });
+            if constexpr (PRO == 1) {
+                // iteration 0 stores K-tile 2 with set 0 and loads K-tile 3's into set 1
+                static_for<2>([&](auto h_c) { pro_load(pro[0], kt0 + 2, h_c); });
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             static_for<4>([&](auto p_c) { load_piece(sa[0], sw[0], kt0 + RING, kt0 + RING < nk, p_c); });
             __syncthreads();
@@ -629,6 +706,113 @@ __device__ __forceinline__ void linear_tile_body(
             store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * TM * 32 + i * 32, M, n0 + wn * TN * 32 + j * 32, N, bias,
                              bn_scale, bn_shift, relu);
     LCREC_GMARK(3);
+    if constexpr (STATS) {
+        // ---- batch statistics of t = acc + bias, per column (see TileExtras).  LDS: the second K-tile buffer, which nobody
+        // reads any more (the epilogue's staging patches are the first buffer).
+        constexpr int RB = BM / 32;                       // 32-row blocks of the tile
+        float *piv = smem + BUF;                          // [BN]  the tile's first row
+        float *red = piv + BN;                            // [RB][BN][2]
+        int *last_sh = reinterpret_cast<int *>(red + RB * BN * 2);
+        const int c = lane & 31, h = lane >> 5;
+        float bj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + c;
+            bj[j] = (bias && col < N) ? bias[col] : 0.f;
+            if (wm == 0 && h == 0) piv[wn * TN * 32 + j * 32 + c] = acc[0][j][0] + bj[j];      // row m0 (< M: the tile exists)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float pv = piv[wn * TN * 32 + j * 32 + c];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int64_t rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (rbase + (r & 3) + 8 * (r >> 2) < M) {
+                        const float d = (acc[i][j][r] + bj[j]) - pv;
+                        s1 += d;
+                        s2 = __builtin_fmaf(d, d, s2);
+                    }
+                }
+                s1 += __shfl_xor(s1, 32, 64);             // the two half-waves hold the other 16 rows of the column
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0) {
+                    float *dst = red + (((wm * TM + i) * BN) + wn * TN * 32 + j * 32 + c) * 2;
+                    dst[0] = s1;
+                    dst[1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float s1 = red[tid * 2], s2 = red[tid * 2 + 1];
+#pragma unroll
+            for (int b = 1; b < RB; ++b) { s1 += red[(b * BN + tid) * 2]; s2 += red[(b * BN + tid) * 2 + 1]; }
+            float *rec = ex.stat_partial + ((size_t)bm * 3) * N + n0 + tid;
+            handoff_put(rec, piv[tid]);
+            handoff_put(rec + N, s1);
+            handoff_put(rec + 2 * (size_t)N, s2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave's records have reached memory ...
+        __syncthreads();                                   // ... before ONE thread takes the strip's ticket
+        if (tid == 0) *last_sh = ticket_is_last(ex.tickets + bn, (unsigned)bm_blocks) ? 1 : 0;
+        __syncthreads();
+        if (*last_sh) {
+            // the strip's last tile (uniform over the workgroup): merge the row tiles' (n_T, mean_T, M2_T) in tile order -- the same
+            // bits whichever tile comes last.  The acquire in ticket_is_last + the barrier above make plain loads of the records
+            // valid; all 256 threads fetch a chunk of them into LDS side by side (one memory round trip, not one per tile), then
+            // one thread per column walks the chunk in order.  Two passes (mean, then M2 about it), as lcrec_bn_merge_stats.
+            constexpr int CH = BUF / (3 * BN);            // row tiles per chunk (the first K-tile buffer: the staging patches are done)
+            float *rec_l = smem;
+            const bool mine = tid < BN && n0 + tid < N;
+            const int col = n0 + tid;
+            const float total = (float)M;
+            float acc_mean = 0.f, mean = 0.f, m2 = 0.f;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int b0 = 0; b0 < bm_blocks; b0 += CH) {
+                    const int nb = bm_blocks - b0 < CH ? bm_blocks - b0 : CH;
+                    if (pass == 0 || bm_blocks > CH) {
+                        __syncthreads();
+                        for (int e = tid; e < nb * 3 * BN; e += 256) {
+                            const int cidx = e % BN, bf = e / BN;          // bf = tile * 3 + field
+                            rec_l[e] = n0 + cidx < N ? ex.stat_partial[((size_t)b0 * 3 + bf) * N + n0 + cidx] : 0.f;
+                        }
+                        __syncthreads();
+                    }
+                    if (mine) {
+                        for (int b = 0; b < nb; ++b) {
+                            const int64_t left = M - (int64_t)(b0 + b) * BM;
+                            const float nt = (float)(left < BM ? left : BM);
+                            const float pv = rec_l[(b * 3) * BN + tid], s1 = rec_l[(b * 3 + 1) * BN + tid], s2 = rec_l[(b * 3 + 2) * BN + tid];
+                            const float dm = s1 / nt;
+                            if (pass == 0) {
+                                acc_mean += nt * (pv + dm);
+                            } else {
+                                float m2_t = s2 - s1 * dm;
+                                m2_t = m2_t > 0.f ? m2_t : 0.f;
+                                const float d = (pv + dm) - mean;
+                                m2 += m2_t + nt * (d * d);
+                            }
+                        }
+                    }
+                }
+                if (pass == 0) mean = acc_mean / total;
+            }
+            if (!mine) return;
+            const float rstd = 1.0f / __builtin_sqrtf(m2 / total + ex.eps);
+            const float sc = (ex.gamma ? ex.gamma[col] : 1.0f) * rstd;
+            ex.mean_out[col] = mean;
+            ex.rstd_out[col] = rstd;
+            ex.scale_out[col] = sc;
+            ex.shift_out[col] = __builtin_fmaf(-mean, sc, ex.beta ? ex.beta[col] : 0.0f);
+            if (ex.running_mean) ex.running_mean[col] = (1.0f - ex.momentum) * ex.running_mean[col] + ex.momentum * mean;
+            if (ex.running_var)
+                ex.running_var[col] = (1.0f - ex.momentum) * ex.running_var[col] + ex.momentum * (m2 / (total > 1.f ? total - 1.f : 1.f));
+        }
+    }
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool TA = false, bool TB = false>
@@ -639,6 +823,16 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 {
     linear_tile_body<WAVES_M, WAVES_N, TM, TN, FAST, TA, TB>(A, W, bias, bn_scale, bn_shift, C, M, N, K, relu, bn_blocks, bm_blocks,
                                                              tune, kt_per_split, split_stride, blockIdx.x, blockIdx.y);
+}
+
+// The training step's forward product (lcrec_linear_bn_forward): register-buffered tiles only, extras by value.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int PRO, bool STATS>
+__global__ __launch_bounds__(256) void linear_train_fwd_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                               const float *__restrict__ bias, float *__restrict__ C, int64_t M, int N,
+                                                               int K, int bn_blocks, int bm_blocks, int tune, TileExtras ex)
+{
+    linear_tile_body<WAVES_M, WAVES_N, TM, TN, true, false, false, PRO, STATS>(A, W, bias, nullptr, nullptr, C, M, N, K, 0, bn_blocks,
+                                                                             bm_blocks, tune, 1 << 30, (int64_t)0, blockIdx.x, 0u, ex);
 }
 
 // Several independent weight-gradient products dW_p = dY_p^T X_p in ONE launch (64 x 64 tiles, both operands k-major):
@@ -653,8 +847,12 @@ struct DwGroup {
     int M[DW_GROUP_MAX], N[DW_GROUP_MAX], K[DW_GROUP_MAX];
     int bn_blocks[DW_GROUP_MAX], bm_blocks[DW_GROUP_MAX], tiles[DW_GROUP_MAX], kt_per_split[DW_GROUP_MAX];
     unsigned wg_start[DW_GROUP_MAX + 1];
+    // (PRO form) the layer input X_p is given before ITS BatchNorm + ReLU: u = max(x * xs[col] + xh[col], lo); NULL = as it is
+    const float *xs[DW_GROUP_MAX], *xh[DW_GROUP_MAX];
+    float lo[DW_GROUP_MAX];
 };
 
+template <bool PRO>
 __global__ __launch_bounds__(256) void linear_dw_grouped_kernel(DwGroup g)
 {
     int p = 0;
@@ -662,9 +860,15 @@ __global__ __launch_bounds__(256) void linear_dw_grouped_kernel(DwGroup g)
     while (p + 1 < g.count && blockIdx.x >= g.wg_start[p + 1]) ++p;
     const unsigned local = blockIdx.x - g.wg_start[p];
     const unsigned tile = local % (unsigned)g.tiles[p], split = local / (unsigned)g.tiles[p];
-    linear_tile_body<2, 2, 1, 1, true, true, true>(g.A[p], g.B[p], nullptr, nullptr, nullptr, g.C[p], g.M[p], g.N[p], g.K[p], 0,
-                                                   g.bn_blocks[p], g.bm_blocks[p], 1, g.kt_per_split[p],
-                                                   (int64_t)g.M[p] * g.N[p], tile, split);
+    TileExtras ex = {};
+    if constexpr (PRO) {
+        ex.in_scale = g.xs[p];
+        ex.in_shift = g.xh[p];
+        ex.in_lo = g.lo[p];
+    }
+    linear_tile_body<2, 2, 1, 1, true, true, true, PRO ? 2 : 0>(g.A[p], g.B[p], nullptr, nullptr, nullptr, g.C[p], g.M[p], g.N[p], g.K[p], 0,
+                                                              g.bn_blocks[p], g.bm_blocks[p], 1, g.kt_per_split[p],
+                                                              (int64_t)g.M[p] * g.N[p], tile, split, ex);
 }
 
 struct DwReduce {
@@ -1526,6 +1730,7 @@ int linear_backward_weights(const lcrec_dw_problem *pr, int count, void *workspa
     DwReduce r = {};
     char *ws = reinterpret_cast<char *>(workspace);
     unsigned wg = 0, rwg = 0;
+    bool any_pro = false;
     for (int i = 0; i < count; ++i) {
         const lcrec_dw_problem &q = pr[i];
         if (!q.gy || !q.x || !q.gw) return fail(LCREC_EINVAL, "linear_backward_weights: NULL pointer in problem %d", i);
@@ -1543,6 +1748,11 @@ int linear_backward_weights(const lcrec_dw_problem *pr, int count, void *workspa
         const int bn_blocks = (q.in_dim + 63) / 64;
         const int64_t tiles = ((bm_blocks + 7) / 8) * 8 * bn_blocks;      // XCD-aware numbering has holes (see linear_tile_body)
         g.A[i] = q.gy; g.B[i] = q.x;
+        if ((q.x_scale == nullptr) != (q.x_shift == nullptr)) return fail(LCREC_EINVAL, "linear_backward_weights: problem %d: x_scale and x_shift go together", i);
+        if (((uintptr_t)q.x_scale | (uintptr_t)q.x_shift) & 15) return fail(LCREC_EINVAL, "linear_backward_weights: x_scale / x_shift must be 16-byte aligned");
+        g.xs[i] = q.x_scale; g.xh[i] = q.x_shift;
+        g.lo[i] = (q.x_scale && q.x_relu) ? 0.0f : -__builtin_inff();
+        any_pro = any_pro || q.x_scale != nullptr;
         g.M[i] = q.out_dim; g.N[i] = q.in_dim; g.K[i] = (int)q.n;
         g.bn_blocks[i] = bn_blocks; g.bm_blocks[i] = (int)bm_blocks; g.tiles[i] = (int)tiles;
         g.kt_per_split[i] = splits > 1 ? (nk + splits - 1) / splits : 1 << 30;
@@ -1565,9 +1775,79 @@ int linear_backward_weights(const lcrec_dw_problem *pr, int count, void *workspa
     g.wg_start[count] = wg;
     r.wg_start[r.count] = rwg;
     TraceScope trace(K_LINEAR_64x64, stream);
-    hipLaunchKernelGGL(linear_dw_grouped_kernel, dim3(wg), dim3(256), 0, stream, g);
+    if (any_pro) hipLaunchKernelGGL(linear_dw_grouped_kernel<true>, dim3(wg), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(linear_dw_grouped_kernel<false>, dim3(wg), dim3(256), 0, stream, g);
     if (r.count) hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3(rwg), dim3(256), 0, stream, r);
     return check_launch("linear_dw_grouped_kernel");
+}
+
+// ---- lcrec_linear_bn_forward: the training step's Linear with its input's BatchNorm + ReLU folded into the operand staging
+// and its output's batch statistics taken in the epilogue (TileExtras)
+static int train_tile_shape(int64_t n, int out_dim)
+{
+    if (out_dim > 64) return wide_tiles_fill(n, out_dim) ? 4 : 0;       // 64 x 128 : 64 x 64
+    return out_dim > 32 ? 0 : 3;                                        // 64 x 64 : 128 x 32
+}
+
+size_t linear_bn_forward_workspace(int64_t n, int out_dim)
+{
+    const int bm = train_tile_shape(n, out_dim) == 3 ? 128 : 64;
+    return (size_t)((n + bm - 1) / bm) * 3 * (size_t)out_dim * sizeof(float);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static int launch_train_fwd(const float *x, int64_t n, int in_dim, const float *W, const float *b, int out_dim, float *t,
+                            bool pro, bool stats, const TileExtras &ex, hipStream_t stream)
+{
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    const int64_t bm_blocks = (n + BM - 1) / BM;
+    const int bn_blocks = (out_dim + BN - 1) / BN;
+    const int64_t grid = ((bm_blocks + 7) / 8) * 8 * bn_blocks;
+    TraceScope trace(BM == 64 ? K_LINEAR_64x64 : K_LINEAR_128x32, stream);
+#define LCREC_TRAIN_LAUNCH(P, S)                                                                                                  \
+    hipLaunchKernelGGL((linear_train_fwd_kernel<WAVES_M, WAVES_N, TM, TN, P, S>), dim3((unsigned)grid), dim3(256), 0, stream, x, W, b, t, \
+                       n, out_dim, in_dim, bn_blocks, (int)bm_blocks, 1, ex)
+    if (pro && stats) LCREC_TRAIN_LAUNCH(1, true);
+    else if (pro) LCREC_TRAIN_LAUNCH(1, false);
+    else LCREC_TRAIN_LAUNCH(0, true);
+#undef LCREC_TRAIN_LAUNCH
+    return check_launch("linear_train_fwd_kernel");
+}
+
+int linear_bn_forward(const float *x, int64_t n, int in_dim, const float *in_scale, const float *in_shift, int in_relu,
+                      const float *W, const float *b, int out_dim, float *t_out, int want_stats, const float *gamma,
+                      const float *beta, float eps, float momentum, float *running_mean, float *running_var, float *mean_out,
+                      float *rstd_out, float *scale_out, float *shift_out, void *workspace, size_t workspace_bytes,
+                      unsigned *tickets, hipStream_t stream)
+{
+    if (!x || !W || !t_out) return fail(LCREC_EINVAL, "linear_bn_forward: NULL pointer");
+    if (n < 1 || in_dim <= 0 || out_dim <= 0) return fail(LCREC_EINVAL, "linear_bn_forward: bad shape");
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return fail(LCREC_EINVAL, "linear_bn_forward: in_scale and in_shift go together");
+    const bool pro = in_scale != nullptr, stats = want_stats != 0;
+    if (!pro && !stats) return linear_forward(x, n, in_dim, W, b, nullptr, nullptr, 0, out_dim, t_out, stream);
+    if (in_dim % BK != 0 || out_dim % 4 != 0)
+        return fail(LCREC_EUNSUPPORTED, "linear_bn_forward: in_dim=%d must be a multiple of 32, out_dim=%d of 4", in_dim, out_dim);
+    if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)in_scale | (uintptr_t)in_shift) & 15)
+        return fail(LCREC_EINVAL, "linear_bn_forward: operands must be 16-byte aligned");
+    if (((n + 127) / 128) * ((out_dim + 127) / 128) >= 512 || (int64_t)in_dim * 4 * (n + 128) >= (1ll << 31) || out_dim > 64 * 64)
+        return fail(LCREC_EUNSUPPORTED, "linear_bn_forward: sized for training batches (n=%lld, out_dim=%d)", (long long)n, out_dim);
+    if (stats) {
+        if (n < 2) return fail(LCREC_EINVAL, "linear_bn_forward: training-mode BatchNorm needs more than 1 row (n=%lld)", (long long)n);
+        if (!mean_out || !rstd_out || !scale_out || !shift_out || !tickets) return fail(LCREC_EINVAL, "linear_bn_forward: NULL statistics output or tickets");
+        if (!workspace || workspace_bytes < linear_bn_forward_workspace(n, out_dim))
+            return fail(LCREC_EWORKSPACE, "linear_bn_forward: workspace %zu B < required %zu B", workspace_bytes, linear_bn_forward_workspace(n, out_dim));
+    }
+    TileExtras ex = {};
+    ex.in_scale = in_scale; ex.in_shift = in_shift; ex.in_lo = (pro && in_relu) ? 0.0f : -__builtin_inff();
+    ex.stat_partial = reinterpret_cast<float *>(workspace); ex.tickets = tickets;
+    ex.gamma = gamma; ex.beta = beta; ex.eps = eps; ex.momentum = momentum;
+    ex.running_mean = running_mean; ex.running_var = running_var;
+    ex.mean_out = mean_out; ex.rstd_out = rstd_out; ex.scale_out = scale_out; ex.shift_out = shift_out;
+    switch (train_tile_shape(n, out_dim)) {
+    case 4: return launch_train_fwd<2, 2, 1, 2>(x, n, in_dim, W, b, out_dim, t_out, pro, stats, ex, stream);
+    case 3: return launch_train_fwd<4, 1, 1, 1>(x, n, in_dim, W, b, out_dim, t_out, pro, stats, ex, stream);
+    default: return launch_train_fwd<2, 2, 1, 1>(x, n, in_dim, W, b, out_dim, t_out, pro, stats, ex, stream);
+    }
 }
 
 int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const float *b,

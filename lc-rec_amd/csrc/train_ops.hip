@@ -177,15 +177,27 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const floa
                                                                        const float *__restrict__ y, int64_t n, int F,
                                                                        const float *__restrict__ gamma, const float *__restrict__ mean,
                                                                        const float *__restrict__ rstd, int relu, float *dt,
-                                                                       float *dgamma, float *dbeta, float *dbias)
+                                                                       float *dgamma, float *dbeta, float *dbias,
+                                                                       const float *__restrict__ fold_scale,
+                                                                       const float *__restrict__ fold_shift)
 {
     __shared__ float sm[CR_WAVES][COLS];
     constexpr int RGS = Strip<COLS>::RGS;
     const Strip<COLS> st(F);
     const int col = st.live ? st.col : 0;
     const float mu = mean[col], rs = rstd[col], gm = gamma ? gamma[col] : 1.0f;
-    const float *gc = gy + col, *tc = t + col, *yc = relu ? y + col : nullptr;
-    auto gval = [&](int64_t r) { float g = gc[r * F]; if (relu && !(yc[r * F] > 0.f)) g = 0.f; return g; };
+    const float *gc = gy + col, *tc = t + col, *yc = (relu && y) ? y + col : nullptr;
+    // the ReLU mask from the stored activation y, or -- when the forward never wrote one (lcrec_linear_bn_forward hands t to the
+    // next layer, which applies max(t * scale + shift, 0) itself) -- from the same fused expression the consumer evaluated
+    const float fs = (relu && !y) ? fold_scale[col] : 0.f, fh = (relu && !y) ? fold_shift[col] : 0.f;
+    auto gval = [&](int64_t r) {
+        float g = gc[r * F];
+        if (relu) {
+            const bool on = yc ? yc[r * F] > 0.f : __builtin_fmaf(tc[r * F], fs, fh) > 0.f;
+            if (!on) g = 0.f;
+        }
+        return g;
+    };
     float gv[CACHED ? CR_MAXR : 1], xv[CACHED ? CR_MAXR : 1];     // CACHED: the lane's masked gradients and xhat, read once
     float db = 0.f, dg = 0.f;
     if (CACHED) {
@@ -686,13 +698,16 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
 }
 
 int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int F, const float *gamma, const float *mean,
-                     const float *rstd, int relu, float *dt, float *dgamma, float *dbeta, float *dbias, hipStream_t stream)
+                     const float *rstd, int relu, float *dt, float *dgamma, float *dbeta, float *dbias, const float *fold_scale,
+                     const float *fold_shift, hipStream_t stream)
 {
     if (n == 0 || F == 0) return LCREC_OK;
-    if (!gy || !t || !mean || !rstd || !dt || (relu && !y)) return fail(LCREC_EINVAL, "bn_relu_backward: NULL pointer");
+    if (!gy || !t || !mean || !rstd || !dt || (relu && !y && !(fold_scale && fold_shift)))
+        return fail(LCREC_EINVAL, "bn_relu_backward: NULL pointer (with relu: y, or fold_scale and fold_shift)");
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_backward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_BWD, stream);
-    LCREC_STRIP_LAUNCH_N(bn_relu_backward_kernel, F, n, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias);
+    LCREC_STRIP_LAUNCH_N(bn_relu_backward_kernel, F, n, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias,
+                         fold_scale, fold_shift);
     return check_launch("bn_relu_backward_kernel");
 }
 

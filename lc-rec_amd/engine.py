@@ -48,13 +48,15 @@ _ALIGN = 64     # floats: every parameter starts on a 256-byte boundary of the f
 
 class TrainEngine:
     def __init__(self, model, optimizer, schedule, warmup_steps, total_steps, max_norm=1.0, use_graph=True, use_ema=False,
-                 dist=None, dp_graph="auto"):
+                 dist=None, dp_graph="auto", fuse_bn=None):
         """schedule: "linear" | "constant" (index/trainer.py:83-92) or None (fixed learning rate).
         use_ema: the improve fork's EMA codebook update after every step (index_improve/trainer.py:119).
         dist: an enabled dist.DistContext for item-sharded data parallel (the caller sets dist.set_batch before a step).
         dp_graph: "on" captures the data-parallel step with its RCCL collectives; "off" launches the same line eagerly;
         "auto" = on for a one-rank group (run in the GPU suite), off for more ranks -- UNVERIFIED on more than one GPU."""
         self.model = model
+        # BatchNorm folded into the GEMMs on either side of it (lcrec_linear_bn_forward); LCREC_FUSE_BN=0: the separate kernels
+        self.fuse_bn = (__import__("os").environ.get("LCREC_FUSE_BN", "1") != "0") if fuse_bn is None else bool(fuse_bn)
         self.dist = dist if (dist is not None and dist.enabled) else None
         if self.dist is not None:
             import torch.distributed as tdist
@@ -169,11 +171,35 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ the step, as library calls
     def _mlp_forward(self, mlp, h):
+        """One MLP going forward.  Per layer `saved` gets (layer input, Linear, BatchNorm | None, relu, t, y, mean, rstd,
+        in_fold, out_fold): with FUSED BatchNorm (single process, batch-sized launches -- lcrec_linear_bn_forward) no
+        activation y is ever written: a layer's input is the previous layer's pre-BatchNorm output t plus that BatchNorm's
+        folded (scale, shift) = in_fold, applied by the consumers' operand staging; out_fold is this layer's own."""
         saved = []
         mods = mlp.mlp_layers
-        for g in mlp._groups:
+        groups = mlp._groups
+        fused = self.fuse_bn and self.dist is None and all(
+            ops.linear_bn_supported(h.shape[0], mods[g["linear"]].in_features, mods[g["linear"]].out_features) for g in groups)
+        fold = None                                                          # (scale, shift, relu) of the tensor `h` stands for
+        for g in groups:
             lin = mods[g["linear"]]
             relu = "act" in g
+            if fused:
+                bn = mods[g["bn"]] if "bn" in g else None
+                bn_args = None if bn is None else (bn.weight.data, bn.bias.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+                if fold is None and bn is None:
+                    t = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=relu)       # a plain layer: the ordinary kernel
+                    stats = None
+                else:
+                    if bn is None and relu:
+                        raise ops._lib.LcrecError("engine: a ReLU without BatchNorm after a BatchNorm layer is not a shape MLPLayers builds")
+                    t, stats = ops.linear_bn_forward(h, lin.weight.data, lin.bias.data, in_fold=None if fold is None else fold[:2],
+                                                     in_relu=bool(fold and fold[2]), bn=bn_args)
+                out_fold = None if stats is None else (stats[2], stats[3], relu)
+                saved.append((h, lin, bn, relu, t, None if bn is not None else t, None if stats is None else stats[0],
+                              None if stats is None else stats[1], fold, out_fold))
+                h, fold = t, out_fold
+                continue
             if "bn" in g:
                 bn = mods[g["bn"]]
                 t = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=False)
@@ -185,20 +211,22 @@ class TrainEngine:
                 else:
                     y, mean, rstd = ops.bn_relu_forward(t, bn.weight.data, bn.bias.data, bn.eps, bn.momentum, bn.running_mean,
                                                         bn.running_var, relu=relu)
-                saved.append((h, lin, bn, relu, t, y, mean, rstd))
+                saved.append((h, lin, bn, relu, t, y, mean, rstd, None, None))
             else:
                 y = ops.linear_forward(h, lin.weight.data, lin.bias.data, relu=relu)
-                saved.append((h, lin, None, relu, None, y, None, None))
+                saved.append((h, lin, None, relu, None, y, None, None, None, None))
             h = y
+        if fold is not None:
+            raise ops._lib.LcrecError("engine: the last layer of an MLP has no BatchNorm (layers.py:19-30)")
         return h, saved
 
     def _mlp_backward(self, saved, g, need_input_grad, dw):
         """The dX chain of one MLP: BatchNorm/ReLU backward -> dX GEMM -> next layer.  Weight gradients are leaves of the
         dependency graph and most of them are a handful of tiles: they are queued in `dw` as (dt, layer input, gradient
-        view) and computed by ONE grouped launch at the end of the step (lcrec_linear_backward_weights)."""
+        view[, input fold]) and computed by ONE grouped launch at the end of the step (lcrec_linear_backward_weights)."""
         gv = self.grad_view
         for i in range(len(saved) - 1, -1, -1):
-            h, lin, bn, relu, t, y, mean, rstd = saved[i]
+            h, lin, bn, relu, t, y, mean, rstd, in_fold, out_fold = saved[i]
             if bn is not None and self.dist is not None:
                 sums = ops.bn_backward_reduce(g, t, y, mean, rstd, relu, dbeta_out=gv[bn.bias], dgamma_out=gv[bn.weight])
                 self.dist.all_reduce_(sums)
@@ -207,10 +235,11 @@ class TrainEngine:
                                               dbias_out=gv[lin.bias])
             elif bn is not None:
                 dt, _, _, _ = ops.bn_relu_backward(g, t, y, bn.weight.data, mean, rstd, relu, dgamma_out=gv[bn.weight],
-                                                   dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias])
+                                                   dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias],
+                                                   fold=None if y is not None else out_fold[:2])
             else:
                 dt, _ = ops.relu_bias_backward(g, y, relu, dbias_out=gv[lin.bias], inplace=True)
-            dw.append((dt, h, gv[lin.weight]))
+            dw.append((dt, h, gv[lin.weight]) if in_fold is None else (dt, h, gv[lin.weight], in_fold))
             if i > 0 or need_input_grad:
                 w = lin.weight.data
                 pad = (-w.shape[0]) % 32                # layers._LinearAct.backward: K slice of the k-major dX kernel
@@ -350,7 +379,7 @@ class TrainEngine:
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            ops._ticket(self.device)                     # the capture stream's ticket word (zeroed here, outside the capture)
+            ops._ticket(self.device, force=True)         # the capture stream's ticket word (zeroed here, outside the capture)
         # Data parallel: the process group's watchdog THREAD polls the events of collectives issued before the capture
         # (hipEventQuery); in the default "global" capture mode such a call from any thread is an error that invalidates the
         # capture -- and kills the watchdog, which takes the process down (seen once in ~10 runs).  "thread_local" confines the

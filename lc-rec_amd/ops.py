@@ -93,15 +93,17 @@ _tickets = {}
 USE_TICKETS = __import__("os").environ.get("LCREC_TICKETS", "1") != "0"
 
 
-def _ticket(device):
-    if not USE_TICKETS:
+def _ticket(device, force=False):
+    """int32 [96] zeros: word 0 is the ticket of the reduction tails; words 16 .. 79 are the 64 column-strip tickets of
+    lcrec_linear_bn_forward (force=True: that call has no ticket-less form)."""
+    if not USE_TICKETS and not force:
         return None
     key = (device.index, _stream_int(device.index))
     t = _tickets.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.LcrecError("the stream's ticket word must exist before a graph capture (run the step once eagerly first)")
-        t = _tickets[key] = torch.zeros(16, dtype=torch.int32, device=device)
+        t = _tickets[key] = torch.zeros(96, dtype=torch.int32, device=device)
     return t
 
 
@@ -182,6 +184,44 @@ def linear_forward(x, weight, bias=None, bn_scale=None, bn_shift=None, relu=Fals
     return y
 
 
+def linear_bn_supported(n, in_dim, out_dim):
+    """Whether lcrec_linear_bn_forward takes this shape (a batch-sized launch; include/lcrec.h)."""
+    return (n >= 2 and in_dim % 32 == 0 and out_dim % 4 == 0 and out_dim <= 4096
+            and ((n + 127) // 128) * ((out_dim + 127) // 128) < 512 and in_dim * 4 * (n + 128) < (1 << 31))
+
+
+def linear_bn_forward(x, weight, bias, in_fold=None, in_relu=True, bn=None):
+    """One Linear of a training step with the BatchNorms around it folded in (lcrec_linear_bn_forward):
+    t = max(x * in_fold[0] + in_fold[1], 0 if in_relu) @ weight.T + bias, and -- with bn = (gamma, beta, eps, momentum,
+    running_mean, running_var) -- the batch statistics of t.  Returns (t, None) or (t, (mean, rstd, scale, shift)):
+    scale / shift are this BatchNorm's folded affine, the next layer's in_fold."""
+    lib = _lib.load()
+    x, weight, bias = _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")
+    n, k = x.shape
+    out_dim = weight.shape[0]
+    dev = x.device
+    t = torch.empty((n, out_dim), dtype=torch.float32, device=dev)
+    sc, sh = (None, None) if in_fold is None else (_vec(in_fold[0], "in_scale", k), _vec(in_fold[1], "in_shift", k))
+    stats = None
+    gamma = beta = rm = rv = None
+    eps = momentum = 0.0
+    if bn is not None:
+        gamma, beta, eps, momentum, rm, rv = bn
+        stats = torch.empty((4, out_dim), dtype=torch.float32, device=dev)     # mean, rstd, scale, shift
+        gamma, beta = _vec(gamma, "gamma", out_dim), _vec(beta, "beta", out_dim)
+    with _on(dev):
+        ws = _workspace(lib.lcrec_linear_bn_forward_workspace(n, out_dim), dev) if bn is not None else None
+        tk = _ticket(dev, force=True) if bn is not None else None
+        rc = lib.lcrec_linear_bn_forward(_ptr(x), n, k, _ptr(sc), _ptr(sh), int(bool(in_relu)), _ptr(weight), _ptr(bias), out_dim,
+                                         _ptr(t), int(bn is not None), _ptr(gamma), _ptr(beta), float(eps), float(momentum or 0.0),
+                                         _ptr(rm), _ptr(rv), _ptr(None if stats is None else stats[0]),
+                                         _ptr(None if stats is None else stats[1]), _ptr(None if stats is None else stats[2]),
+                                         _ptr(None if stats is None else stats[3]), _ptr(ws), 0 if ws is None else ws.numel(),
+                                         ctypes.c_void_p(tk.data_ptr() + 64) if tk is not None else None, _stream_ptr())
+    _lib.check(rc, "lcrec_linear_bn_forward")
+    return t, (None if stats is None else (stats[0], stats[1], stats[2], stats[3]))
+
+
 def linear_backward(gy, x, weight, need_gx=True, need_gw=True, gw_out=None):
     """(gx, gw) of y = x W^T for a given gy = dL/dy (autograd's LinearBackward; include/lcrec.h,
     lcrec_linear_backward): gx = gy W, gw = gy^T x, every operand read as stored.  Raises
@@ -212,20 +252,29 @@ def linear_backward(gy, x, weight, need_gx=True, need_gw=True, gw_out=None):
 def linear_backward_weights(problems):
     """Weight gradients of several Linear layers in ONE launch (lcrec_linear_backward_weights): `problems` is a list of
     (gy [n, out], x [n, in], gw_out [out, in]) device tensors; every gw_out is written in place, bit-identical to what
-    linear_backward(gy, x, W, need_gx=False) computes for that layer."""
+    linear_backward(gy, x, W, need_gx=False) computes for that layer.  A fourth entry (scale, shift, relu) makes the layer
+    input max(x * scale + shift, 0 if relu) -- x being a pre-BatchNorm tensor of lcrec_linear_bn_forward -- formed on the fly."""
     lib = _lib.load()
     count = len(problems)
     if count == 0:
         return
     arr = (_lib.DwProblem * count)()
     keep = []
-    for i, (gy, x, gw) in enumerate(problems):
+    for i, prob in enumerate(problems):
+        gy, x, gw = prob[:3]
+        fold = prob[3] if len(prob) > 3 else None
         gy, x = _dev(gy, "gy"), _dev(x, "x")
         n, out_dim = gy.shape
         in_dim = x.shape[1]
         if x.shape[0] != n or tuple(gw.shape) != (out_dim, in_dim) or not gw.is_contiguous() or gw.dtype != torch.float32:
             raise _lib.LcrecError(f"linear_backward_weights: problem {i}: gy {tuple(gy.shape)}, x {tuple(x.shape)}, gw {tuple(gw.shape)}")
-        arr[i] = _lib.DwProblem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), n, in_dim, out_dim)
+        if fold is None:
+            arr[i] = _lib.DwProblem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), n, in_dim, out_dim, None, None, 0)
+        else:
+            fs, fh = _vec(fold[0], "x_scale", in_dim), _vec(fold[1], "x_shift", in_dim)
+            arr[i] = _lib.DwProblem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), n, in_dim, out_dim, fs.data_ptr(), fh.data_ptr(),
+                                    int(bool(fold[2])))
+            keep += [fs, fh]
         keep += [gy, x]
     dev = problems[0][0].device
     with _on(dev):
@@ -634,9 +683,10 @@ def bn_relu_forward(t, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, r
     return y, mean, rstd
 
 
-def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, dbeta_out=None, dbias_out=None):
+def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, dbeta_out=None, dbias_out=None, fold=None):
     """(dt, dgamma, dbeta, dbias) of y = [relu](bn(t)) for gy = dL/dy (see lcrec_bn_relu_backward); the three vector
-    outputs may be given (views of a flat gradient buffer)."""
+    outputs may be given (views of a flat gradient buffer).  y None + fold = (scale, shift): the ReLU mask is recomputed as
+    [t * scale + shift > 0]."""
     lib = _lib.load()
     gy, t = _dev(gy, "gy"), _dev(t, "t")
     y = None if y is None else _dev(y, "y")
@@ -648,7 +698,8 @@ def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, db
     with _on(t.device):
         rc = lib.lcrec_bn_relu_backward(_ptr(gy), _ptr(t), _ptr(y), n, F, _ptr(gamma), _ptr(_vec(mean, "mean", F)),
                                         _ptr(_vec(rstd, "rstd", F)), int(bool(relu)), _ptr(dt), _ptr(dgamma), _ptr(dbeta),
-                                        _ptr(dbias), _stream_ptr())
+                                        _ptr(dbias), _ptr(None if fold is None else _vec(fold[0], "fold_scale", F)),
+                                        _ptr(None if fold is None else _vec(fold[1], "fold_shift", F)), _stream_ptr())
     _lib.check(rc, "lcrec_bn_relu_backward")
     return dt, dgamma, dbeta, dbias
 

@@ -49,6 +49,8 @@ def _load():
     lib.lcrec_oracle_ema_update.restype = ctypes.c_int
     lib.lcrec_oracle_ema_update.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float]
+    lib.lcrec_oracle_affine_relu.restype = ctypes.c_int
+    lib.lcrec_oracle_affine_relu.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, _f32p, _f32p, ctypes.c_int, _f32p]
     return lib
 
 
@@ -102,6 +104,16 @@ def linear(x, W, b=None, bn_scale=None, bn_shift=None, relu=False, threads=1):
         with ThreadPoolExecutor(len(parts)) as ex:
             list(ex.map(lambda t: run(*t), parts))
     return y
+
+
+def affine_relu(x, scale, shift, relu=True):
+    """max(fma(x, scale, shift), 0): a folded training-mode BatchNorm + ReLU as the fused kernels apply it to an operand."""
+    x, scale, shift = _f32(x), _f32(scale), _f32(shift)
+    n, f = x.shape
+    u = np.empty_like(x)
+    rc = lib().lcrec_oracle_affine_relu(_p(x), n, f, _p(scale), _p(shift), int(bool(relu)), _p(u))
+    assert rc == 0
+    return u
 
 
 def rq_assign(z, codebooks, want_resid=False, want_margin=False):

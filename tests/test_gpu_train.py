@@ -203,6 +203,89 @@ def test_clip_and_adamw_match_torch(hip, decoupled, schedule):
     np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("n,k,f", [(1024, 768, 2048), (1024, 2048, 1024), (1000, 256, 128), (475, 128, 64), (1024, 64, 32),
+                                   (2048, 1024, 512), (130, 4096, 2048)])
+def test_linear_bn_forward_is_the_oracle_chain_with_batch_statistics(hip, oracle, n, k, f):
+    """lcrec_linear_bn_forward: the previous layer's BatchNorm + ReLU applied to the operand on its way into LDS
+    (layers.py:25-30 never materialised), the product bit for bit the oracle's fma chains on that operand, and this layer's
+    batch statistics from the epilogue (per-tile partials merged by the last tile of each column strip) against fp64."""
+    ops = hip.ops
+    dev = torch.device(DEV)
+    rs = _rs(40 + n + k + f)
+    tp = gi.f32(rs.standard_normal((n, k)) * 1.5 + 0.3)
+    sc, sh = gi.f32(0.5 + rs.uniform(size=k)), gi.f32(0.3 * rs.standard_normal(k))
+    W, b = gi.f32(rs.standard_normal((f, k)) * (2.0 / (k + f)) ** 0.5), gi.f32(0.1 * rs.standard_normal(f))
+    gamma, beta = gi.f32(1 + 0.1 * rs.standard_normal(f)), gi.f32(0.1 * rs.standard_normal(f))
+    rm0, rv0 = gi.f32(0.1 * rs.standard_normal(f)), gi.f32(0.5 + rs.uniform(size=f))
+    d = lambda a: torch.from_numpy(a.copy()).to(dev)
+    u = oracle.affine_relu(tp, sc, sh, relu=True)
+    want = oracle.linear(u, W, b, threads=8)
+    assert ops.linear_bn_supported(n, k, f)
+    for pro, stats in ((True, True), (False, True), (True, False)):
+        rm, rv = d(rm0), d(rv0)
+        t, st = ops.linear_bn_forward(d(tp) if pro else d(u), d(W), d(b), in_fold=(d(sc), d(sh)) if pro else None, in_relu=True,
+                                      bn=(d(gamma), d(beta), 1e-5, 0.1, rm, rv) if stats else None)
+        assert np.array_equal(t.cpu().numpy(), want), (pro, stats)
+        if not stats:
+            assert st is None
+            continue
+        w64 = want.astype(np.float64)
+        mean, var = w64.mean(0), w64.var(0)
+        rstd = 1.0 / np.sqrt(var + 1e-5)
+        np.testing.assert_allclose(st[0].cpu().numpy(), mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st[1].cpu().numpy(), rstd, rtol=1e-5)
+        np.testing.assert_allclose(st[2].cpu().numpy(), gamma * rstd, rtol=1e-5)
+        np.testing.assert_allclose(st[3].cpu().numpy(), beta - mean * gamma * rstd, rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(rm.cpu().numpy(), 0.9 * rm0 + 0.1 * mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rv.cpu().numpy(), 0.9 * rv0 + 0.1 * var * n / (n - 1), rtol=1e-5)
+    assert int(ops._ticket(dev, force=True).abs().sum()) == 0          # every strip's ticket is back at zero
+    # a second pair of calls gives the same bits (the merge order does not depend on which tile arrives last)
+    a = ops.linear_bn_forward(d(tp), d(W), d(b), in_fold=(d(sc), d(sh)), bn=(d(gamma), d(beta), 1e-5, 0.1, None, None))[1]
+    b2 = ops.linear_bn_forward(d(tp), d(W), d(b), in_fold=(d(sc), d(sh)), bn=(d(gamma), d(beta), 1e-5, 0.1, None, None))[1]
+    assert all(torch.equal(x, y) for x, y in zip(a, b2))
+
+
+def test_folded_batchnorm_operands_in_the_backward_products(hip, oracle):
+    """The consumers of a never-materialised activation: lcrec_linear_backward_weights with (x_scale, x_shift, relu) equals
+    the same launch on the materialised input bit for bit -- also on a ragged batch, whose rows past the end must stay
+    zero -- and lcrec_bn_relu_backward with the mask recomputed from t equals the mask from the stored activation."""
+    ops = hip.ops
+    dev = torch.device(DEV)
+    rs = _rs(77)
+    d = lambda a: torch.from_numpy(a.copy()).to(dev)
+    for n in (1024, 475):
+        probs_f, probs_m = [], []
+        outs_f, outs_m = [], []
+        for k, f in ((768, 2048), (2048, 1024), (256, 128), (64, 32)):
+            x = gi.f32(rs.standard_normal((n, k)))
+            sc, sh = gi.f32(0.5 + rs.uniform(size=k)), gi.f32(0.3 * rs.standard_normal(k))
+            gy = gi.f32(rs.standard_normal((n, f)) * 0.01)
+            u = oracle.affine_relu(x, sc, sh, relu=True)
+            gf, gm = torch.empty((f, k), device=dev), torch.empty((f, k), device=dev)
+            probs_f.append((d(gy), d(x), gf, (d(sc), d(sh), True)))
+            probs_m.append((d(gy), d(u), gm))
+            outs_f.append(gf)
+            outs_m.append(gm)
+        probs_f.append((probs_m[0][0], probs_m[0][1], torch.empty_like(outs_m[0])))          # a problem without a fold in the same launch
+        ops.linear_backward_weights(probs_f)
+        ops.linear_backward_weights(probs_m)
+        for a, b in zip(outs_f, outs_m):
+            assert torch.equal(a, b), n
+        assert torch.equal(probs_f[-1][2], outs_m[0])
+    n, f = 1000, 512
+    t = gi.f32(rs.standard_normal((n, f)))
+    gy = gi.f32(rs.standard_normal((n, f)))
+    gamma = gi.f32(1 + 0.1 * rs.standard_normal(f))
+    mean, var = t.mean(0), t.var(0)
+    rstd = gi.f32(1 / np.sqrt(var + 1e-5))
+    sc = gi.f32(gamma * rstd)
+    sh = gi.f32(0.05 - mean * sc)
+    y = oracle.affine_relu(t, sc, sh, relu=True)
+    a = ops.bn_relu_backward(d(gy), d(t), d(y), d(gamma), d(gi.f32(mean)), d(rstd), True)
+    b = ops.bn_relu_backward(d(gy), d(t), None, d(gamma), d(gi.f32(mean)), d(rstd), True, fold=(d(sc), d(sh)))
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
 def test_ticket_forms_give_the_bits_of_the_two_launch_forms(hip):
     """include/lcrec.h, `ticket` arguments: with the caller's 4-byte word the last workgroup to arrive finishes a partial-sum
     reduction inside the launch -- same order of additions as the finishing launch it replaces, hence the same bits -- and the
