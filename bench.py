@@ -129,9 +129,10 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=12.0):
-    """The reference's CPU path (torch CPU ops of rqvae.py:68-72, restated in oracle/torch_ref.py),
-    batch 4096, timed on this host's cores on a bounded sample."""
+def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=14.0):
+    """The reference's CPU path (torch CPU ops of rqvae.py:68-72, restated in oracle/torch_ref.py) timed on this host's
+    cores on a bounded sample, as BASELINE.md section 4 asks: batch 4096 AND batch 64 (the batch index/generate_indices.py:77-79
+    uses), each the median of >= 3 passes.  `value` is the batch-4096 median (the reference's faster setting)."""
     from oracle import torch_ref
     codes = [int(c.shape[0]) for c in cbs]
     spec = torch_ref.Spec(dims[0], codes, dims[-1], dims[1:-1], sk_epsilons=[0.0] * len(codes))
@@ -144,17 +145,27 @@ def cpu_baseline(x_cpu, dims, Ws, bs, cbs, budget_s=12.0):
         sd[f"rq.vq_layers.{l}.embedding.weight"] = c.cpu()
     cores = host_cores()
     torch.set_num_threads(cores)
-    batch = 4096
-    torch_ref.get_indices(spec, sd, x_cpu[:batch])          # warm-up
-    done, t0 = 0, time.perf_counter()
-    while done < x_cpu.shape[0]:
-        torch_ref.get_indices(spec, sd, x_cpu[done:done + batch])
-        done += min(batch, x_cpu.shape[0] - done)
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "items/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
-            "sample": f"first {done} rows of the same synthetic tensor, batch 4096, fp32, "
+
+    def one_pass(batch, rows):
+        t0 = time.perf_counter()
+        for lo in range(0, rows, batch):
+            torch_ref.get_indices(spec, sd, x_cpu[lo:min(rows, lo + batch)])
+        return rows / (time.perf_counter() - t0)
+
+    res = {}
+    for batch, share in ((4096, 0.55), (64, 0.45)):
+        torch_ref.get_indices(spec, sd, x_cpu[:batch])          # warm-up
+        probe_rows = min(x_cpu.shape[0], 8 * batch if batch >= 4096 else 64 * batch)
+        rate = one_pass(batch, probe_rows)
+        # three passes inside this batch size's share of the budget, each over the same leading rows of the sample
+        rows = int(max(batch, min(x_cpu.shape[0], rate * budget_s * share / 3.3)))
+        rows -= rows % batch
+        passes = sorted(one_pass(batch, rows) for _ in range(3))
+        res[batch] = {"median": passes[1], "passes": [round(v, 1) for v in passes], "rows_per_pass": rows}
+    return {"value": res[4096]["median"], "unit": "items/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
+            "batch_4096": res[4096], "batch_64": res[64],
+            "sample": f"leading rows of the same synthetic tensor ({res[4096]['rows_per_pass']} per pass at batch 4096, "
+                      f"{res[64]['rows_per_pass']} at batch 64 = generate_indices.py's), median of 3 passes each, fp32, "
                       f"oracle/torch_ref.get_indices (torch CPU ops of rqvae.py:68-72)"}
 
 
@@ -204,6 +215,61 @@ def secondary_metrics(dev, cbs, ks):
     return out
 
 
+def dp_training_secondary(device, world, rank, dp_graph):
+    """N > 1 (or a one-rank group): the shipped recipe's training step as item-sharded data parallel -- every rank 1024 rows of
+    a global batch of 1024 x N (weak), the exchanges of DESIGN.md section 6 in the step (BatchNorm statistics, the Sinkhorn
+    level's rows, losses, the flat gradient buffer in two asynchronous spans) -- launched eagerly, and (--dp-graph) captured
+    in the step's hipGraph.  After K steps every rank's parameter checksum is all-gathered: `train_ranks_seen` ranks reported,
+    and they must agree (same initial weights, same global gradients)."""
+    import torch.distributed as dist
+    import lcrec_amd
+    from lcrec_amd import dist as ldist
+    from lcrec_amd.engine import TrainEngine
+    out = {}
+    ctx = ldist.adopt(device)
+    try:
+        for mode in (["off", "on"] if dp_graph else ["off"]):
+            torch.manual_seed(2024)                                   # the same initial weights on every rank
+            model = lcrec_amd.RQVAE(in_dim=768, num_emb_list=[256] * 4, e_dim=32, layers=HIDDEN, bn=True, kmeans_init=False,
+                                    sk_epsilons=[0.0, 0.0, 0.0, 0.003], sk_iters=50).to(device)
+            model.train()
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+            eng = TrainEngine(model, opt, "linear", 10, 10_000, dist=ctx, dp_graph=mode)
+            g = torch.Generator(device=device).manual_seed(77 + rank)
+            batch = torch.randn((1024, 768), generator=g, device=device)
+            ctx.set_batch(1024, 1024 * world)
+            for _ in range(5):
+                eng.step(batch)
+            dist.barrier()
+            torch.cuda.synchronize()
+            steps = 30
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.step(batch)
+            dist.barrier()
+            torch.cuda.synchronize()
+            ms = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+            eng.end_epoch(None)
+            mine = torch.stack([torch.tensor(float(rank), dtype=torch.float64, device=device), eng.flat_p.double().sum()])
+            got = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine)
+            got = torch.stack(got).cpu()
+            key = "graph" if mode == "on" else "eager"
+            out[f"dp_train_step_ms_{key}"] = float(ms.item())
+            out[f"dp_train_items_per_s_{key}"] = 1024 * world / (float(ms.item()) * 1e-3)
+            out[f"dp_train_graph_replays_{key}"] = eng.graph_replays
+            out["dp_collectives_per_step"] = eng.collectives // max(1, eng.host_steps)
+            out["train_ranks_seen"] = int(got[:, 0].unique().numel())
+            out[f"train_param_checksums_agree_{key}"] = bool((got[:, 1] == got[0, 1]).all())
+            del eng, model, opt
+    finally:
+        ldist.release()
+    out["dp_train_config"] = ("batch 1024 per rank (global 1024 x N) x 768-d, 4 x 256 codes, Sinkhorn on the last level over the gathered "
+                              "global batch, bn=True with global-batch statistics, AdamW + clip on the all-reduced gradient")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +284,10 @@ def main():
     ap.add_argument("--rehearse-rccl", action="store_true",
                     help="with --gpus 1: build a ONE-rank nccl (= RCCL) process group and run the N>1 code path through it "
                          "(barriers, the MAX all-reduce of the time, the all-gather behind ranks_seen)")
+    ap.add_argument("--dp-graph", action="store_true",
+                    help="N > 1: also time the data-parallel training step with its collectives CAPTURED in the hipGraph "
+                         "(unverified on more than one GPU; default: eager collectives only)")
+    ap.add_argument("--no-dp-train", action="store_true", help="N > 1: skip the data-parallel training-step figure")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo = rehearsal of the N>1 code path, "
                          "ranks may then share one GPU")
@@ -396,6 +466,30 @@ def main():
         "kernel_ms": {k: round(v[1], 3) for k, v in trace.items()},
     }
 
+    # the quantiser kernel beside it (BASELINE north_star: "HBM GB/s on the argmin sweep and MFMA utilisation on the distance GEMM"):
+    # one launch per pass over all n items; it never materialises the [n, K] distance matrix the reference sweeps (vq.py:71-75)
+    rq_launches, rq_ms = trace.get("rq_assign", (0, 0.0))
+    rq_flops = 2.0 * E_DIM * sum(ks) * n                       # per launch (all levels that fit LDS together run in one launch)
+    rq_bytes = (4.0 * E_DIM + 8.0 * len(ks)) * n
+    rq_launches_per_pass = max(1, rq_launches // max(1, args.steps))
+    rq_avg_ms = rq_ms / rq_launches if rq_launches else None
+    rq_ach = (rq_flops / rq_launches_per_pass) / (rq_avg_ms * 1e-3) / 1e12 if rq_avg_ms else None
+    rq_traffic = None
+    if os.path.exists(pmc_file):
+        with open(pmc_file) as fh:
+            rq_traffic = json.load(fh).get(args.workload, {}).get("rq_assign", {}).get("hbm_bytes_per_launch")
+    roofline_rq = {
+        "kernel": "rq_assign", "bound": "mfma", "achieved": rq_ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": (rq_ach / PEAK_F32_MFMA_TFLOPS) if rq_ach else None, "launches": rq_launches, "avg_launch_ms": rq_avg_ms,
+        "flops_per_launch": rq_flops / rq_launches_per_pass, "algorithmic_bytes_per_launch": rq_bytes / rq_launches_per_pass,
+        "hbm_gbps_algorithmic": (rq_bytes / rq_launches_per_pass) / (rq_avg_ms * 1e-3) / 1e9 if rq_avg_ms else None,
+        "hbm_peak_gbps": PEAK_HBM_GBPS, "traffic": rq_traffic,
+        "mfma_counters": "profiles/r03_pmc_mfma.txt (SQ_VALU_MFMA_BUSY_CYCLES per launch: 0.62 of the pipe cycles at 1 M items)",
+        "note": "the reference materialises the [n, K] fp32 distance matrix per level (8 KB/item at 4 x 256) and sweeps it for the "
+                "argmin; this kernel keeps it in MFMA accumulators, so its HBM traffic is the 160 B/item of latents in and indices out",
+    }
+
+    out = None
     if rank == 0:
         total_items = n * world * args.steps
         value = total_items / elapsed
@@ -408,7 +502,7 @@ def main():
                        "e_dim": E_DIM, "levels": len(ks), "codes_per_level": ks[0], "sharding": f"items/{world}",
                        "chunk_pipelines": pipelines,
                        "flop_per_item": 2 * macs_all, "bytes_per_item": 4 * wl["in_dim"] + 8 * len(ks)},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_rq_assign": roofline_rq,
             "e2e_mfma_frac": value / world * 2 * macs_all / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "ranks_seen": ranks_seen, "idx_checksums": checksums,
             "neartie_rows": neartie_rows, "neartie_tau": ops.NEARTIE_TAU,
@@ -435,6 +529,29 @@ def main():
                     out["secondary"] = secondary_metrics(device, cbs, ks)
                 except Exception as err:                       # never at the expense of the line itself
                     out["secondary"] = {"error": f"{type(err).__name__}: {err}"}
+    # N > 1 (every rank takes part): the data-parallel training step as a secondary figure, under a watchdog -- a hang in it
+    # (this path has never run on more than one GPU) must not cost the line: after 240 s rank 0 prints the line without it
+    dp = None
+    if use_dist and args.backend == "nccl" and not args.no_dp_train and not args.no_secondary:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["secondary_dp"] = {"error": "timeout after 240 s (data-parallel training step)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(240.0, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            dp = dp_training_secondary(device, world, rank, args.dp_graph)
+        except Exception as err:
+            dp = {"error": f"{type(err).__name__}: {err}"}
+        timer.cancel()
+    if rank == 0:
+        if dp is not None:
+            out["secondary_dp"] = dp
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -311,6 +311,22 @@ def init_from_env(args=None, backend=None, force=False):
     return _CTX
 
 
+def adopt(device):
+    """A DistContext over a process group somebody else has already initialised (bench.py): no environment reading."""
+    global _CTX
+    if not tdist.is_initialized():
+        _CTX = DistContext(device=device)
+        return _CTX
+    _CTX = DistContext(rank=tdist.get_rank(), world_size=tdist.get_world_size(), device=torch.device(device), enabled=True)
+    return _CTX
+
+
+def release():
+    """Forget the current context (the process group itself is the owner's to destroy)."""
+    global _CTX
+    _CTX = DistContext()
+
+
 def attach(trainer, ctx):
     """Make a Trainer data-parallel: identical initial weights, one checkpoint directory (rank 0's), and the bucketed
     gradient all-reduce.  BatchNorm needs no module surgery: layers._BatchNormAct takes its statistics over the global

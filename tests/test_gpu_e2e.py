@@ -166,7 +166,7 @@ def test_bench_line_and_its_collective_path_over_a_one_rank_rccl_group(hip):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--items", "150000", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--rehearse-rccl"], capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--rehearse-rccl", "--dp-graph"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and len(line["idx_checksums"]) == 1
@@ -176,3 +176,9 @@ def test_bench_line_and_its_collective_path_over_a_one_rank_rccl_group(hip):
     assert line["parity_mismatch_rows"] == 0 and 0 <= line["neartie_rows"] < 0.01 * 150000
     sec = line["secondary"]             # SURVEY.md section 8d's secondary figures ride along, outside the timed region
     assert "error" not in sec and sec["quantizer_only_items_per_s"] > 1e8 and 0.3 < sec["train_step_ms"] < 20.0
+    rq = line["roofline_rq_assign"]     # the quantiser's own roofline object (north_star: MFMA utilisation on the distance GEMM)
+    assert rq["kernel"] == "rq_assign" and 0.2 < rq["frac"] < 1.0 and rq["hbm_gbps_algorithmic"] > 50
+    dp = line["secondary_dp"]           # the data-parallel training step through the one-rank group: eager and captured exchanges
+    assert "error" not in dp and dp["train_ranks_seen"] == 1 and dp["dp_collectives_per_step"] >= 20
+    assert dp["train_param_checksums_agree_eager"] and dp["train_param_checksums_agree_graph"]
+    assert 0.3 < dp["dp_train_step_ms_eager"] < 50 and dp["dp_train_graph_replays_graph"] > 0 and dp["dp_train_graph_replays_eager"] == 0
