@@ -195,6 +195,78 @@ def resolve_collisions(model, idx, resid_last, ks, max_rounds=MAX_ROUNDS, on_rou
     return idx, history
 
 
+# ---- opt-in: re-evaluate near-tie items in the reference's own operation order (--recheck_neartie) -----------------------------
+def reference_order_indices(state_dict, n_layers, bn, levels, x, eps=1e-5):
+    """RQVAE.get_indices(x, use_sk=False) (rqvae.py:68-72) as the reference's torch CPU op sequence on ONE batch `x` (a CPU
+    float tensor): nn.Linear / BatchNorm1d(eval) / ReLU per encoder layer (layers.py:18-30,42), then per level
+    d = sum(x^2) + sum(w^2)^T - 2 x w^T, argmin, gather, straight-through, residual (vq.py:71-95, rq.py:45-48).
+    This is the ONE place the product computes on the host: by request, for the ~0.1 % of items whose assignment hangs on
+    the last bits of d -- which bits come out depends on the BLAS under torch (MKL's blocking changes with the batch size and
+    the CPU), so the call reproduces "the reference's CPU run" only on a host like the reference's; DESIGN.md section 2.1.
+    Returns (indices int64 [n, L], residual entering the last level [n, e])."""
+    import torch.nn.functional as F
+    step = 4 if bn else 3
+    h = x
+    for l in range(n_layers):
+        slot = l * step + 1
+        h = F.linear(h, state_dict[f"encoder.mlp_layers.{slot}.weight"], state_dict[f"encoder.mlp_layers.{slot}.bias"])
+        if l != n_layers - 1:
+            if bn:
+                b = f"encoder.mlp_layers.{slot + 1}"
+                h = F.batch_norm(h, state_dict[b + ".running_mean"], state_dict[b + ".running_var"], state_dict[b + ".weight"],
+                                 state_dict[b + ".bias"], False, 0.1, eps)
+            h = F.relu(h)
+    residual, cols, before_last = h, [], h
+    for l in range(levels):
+        w = state_dict[f"rq.vq_layers.{l}.embedding.weight"]
+        if l == levels - 1:
+            before_last = residual
+        d = torch.sum(residual ** 2, dim=1, keepdim=True) + torch.sum(w ** 2, dim=1, keepdim=True).t() \
+            - 2 * torch.matmul(residual, w.t())
+        idx = torch.argmin(d, dim=-1)
+        q = F.embedding(idx, w)
+        q = residual + (q - residual).detach()
+        residual = residual - q
+        cols.append(idx)
+    return torch.stack(cols, dim=-1), before_last
+
+
+@torch.no_grad()
+def recheck_neartie(state_dict, args, data, idx, resid_last, flags, batch_size=64):
+    """For every item flagged by the near-tie audit, recompute its tuple the way index/generate_indices.py:77-79 computes it
+    -- the reference's op sequence on the CPU, on the very 64-row batch the reference's DataLoader would have put the item in
+    (shuffle=False: batch b = items 64 b .. 64 b + 63) -- and overwrite it; items whose code changed before the last level also
+    get that evaluation's last-level residual (the conflict rounds re-assign from it).  `data`: EmbDataset or a host array.
+    Returns (items re-evaluated, items whose tuple changed)."""
+    flagged = torch.nonzero(flags != 0).flatten().cpu().numpy()
+    if flagged.size == 0:
+        return 0, 0
+    sd = {k: v.detach().to("cpu", torch.float32) if v.dtype.is_floating_point else v.detach().cpu() for k, v in state_dict.items()}
+    n_layers = len(args.layers) + 1
+    levels = idx.shape[1]
+    rows = data.embeddings if isinstance(data, EmbDataset) else data
+    n = idx.shape[0]
+    changed = 0
+    new_idx, new_res = [], []
+    for b in np.unique(flagged // batch_size):
+        lo, hi = int(b) * batch_size, min(n, (int(b) + 1) * batch_size)
+        x = torch.from_numpy(np.ascontiguousarray(rows[lo:hi], dtype=np.float32))
+        bi, br = reference_order_indices(sd, n_layers, bool(args.bn), levels, x)
+        mine = flagged[(flagged >= lo) & (flagged < hi)] - lo
+        new_idx.append(bi[mine])
+        new_res.append(br[mine])
+    new_idx, new_res = torch.cat(new_idx).to(idx.device), torch.cat(new_res).to(resid_last.device)
+    where = torch.from_numpy(flagged).to(idx.device)
+    old = idx[where]
+    differ = (old != new_idx).any(1)
+    changed = int(differ.sum())
+    idx[where] = new_idx
+    early = (old[:, :-1] != new_idx[:, :-1]).any(1) if levels > 1 else torch.zeros_like(differ)
+    if bool(early.any()):
+        resid_last[where[early]] = new_res[early]
+    return int(flagged.size), changed
+
+
 def tokens_for(idx_rows):
     """[[i, j, ...], ...] -> [["<a_i>", "<b_j>", ...], ...] (:83-92)."""
     L = len(idx_rows[0]) if idx_rows else 0
@@ -259,8 +331,10 @@ def sharded_assign(ctx, data, assign_fn, device):
     return ctx.gather_rows(idx), ctx.gather_rows(resid_last), ks
 
 
-def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True, ctx=None, trust_checkpoint=False):
+def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=True, ctx=None, trust_checkpoint=False,
+             recheck=False):
     """Whole flow of generate_indices.py:51-145.  Returns a dict of the statistics it prints.
+    recheck: re-evaluate the near-tie items of pass 1 in the reference's CPU operation order (recheck_neartie).
 
     Under torchrun (ctx = dist.init_from_env()) pass 1 is item-sharded over the ranks and each conflict round's
     groups are sharded too (resolve_collisions); rank 0 writes the file."""
@@ -282,6 +356,18 @@ def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=Tr
     # near-tie audit of pass 1: items whose two best codes at some level are closer than the rounding noise of
     # vq.py:71-73 -- the only ones a CPU run of the reference could index differently (ops.NEARTIE_TAU)
     neartie_items = int(ctx.sum_int(int((audit["neartie"] != 0).sum())))
+    rechecked = (0, 0)
+    if recheck:
+        flags = ctx.gather_rows(audit["neartie"]) if ctx.enabled else audit["neartie"]
+        if lead:
+            rechecked = recheck_neartie(ckpt["state_dict"], args, data, idx, resid_last, flags)
+        if ctx.enabled:                                    # rank 0's host decides (ranks on other CPUs could round differently)
+            ctx.broadcast_(idx)
+            ctx.broadcast_(resid_last)
+        if lead:
+            log.info("--recheck_neartie: %d near-tie items re-evaluated with the reference's torch CPU ops on their batch-64 "
+                     "neighbours, %d tuples changed", *rechecked)
+        first_pass = idx.clone()
 
     def show(round_no, n_groups):
         if verbose:
@@ -293,7 +379,7 @@ def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=Tr
     n = idx.shape[0]
     stats = {"items": n, "max_conflicts": final["max_count"], "collision_rate": (n - final["unique"]) / n if n else 0.0,
              "rounds": len(history), "groups_per_round": history, "neartie_items": neartie_items,
-             "neartie_tau": ops.NEARTIE_TAU}
+             "neartie_tau": ops.NEARTIE_TAU, "rechecked_items": rechecked[0], "recheck_changed": rechecked[1]}
     if lead:
         log.info("near-tie items in pass 1: %d of %d (top-2 code gap <= %.3g x distance magnitude at some level); only "
                  "these could receive a different tuple from a CPU run of the reference", neartie_items, n, ops.NEARTIE_TAU)
@@ -315,6 +401,10 @@ def main(argv=None):
     ap.add_argument("--output_dir", type=str, required=True)
     ap.add_argument("--data_path", type=str, default=None, help="override the data path stored in the checkpoint")
     ap.add_argument("--device", type=str, default="cuda:0")
+    ap.add_argument("--recheck_neartie", action="store_true",
+                    help="re-evaluate the ~0.1 %% of items flagged by the near-tie audit with the reference's own torch CPU op "
+                         "sequence on the 64-row batches generate_indices.py:77-79 forms, and use those tuples (the only items a "
+                         "CPU run of the reference can index differently; the outcome depends on the host's BLAS)")
     ap.add_argument("--trust_checkpoint", action="store_true",
                     help="load the checkpoint with the unrestricted unpickler (executes code from the file)")
     a = ap.parse_args(argv)
@@ -323,7 +413,7 @@ def main(argv=None):
     out = os.path.join(a.output_dir, f"{a.dataset}.index.json")
     try:
         return generate(a.ckpt_path, out, device=a.device, data_path=a.data_path, ctx=ctx,
-                        trust_checkpoint=a.trust_checkpoint)
+                        trust_checkpoint=a.trust_checkpoint, recheck=a.recheck_neartie)
     finally:
         ldist.shutdown(ctx)
 

@@ -333,3 +333,44 @@ def test_kmeans_host_path_reproduces_reference_fixture():
         assert c.dtype == torch.float32 and tuple(c.shape) == (K, 32)
         # sklearn's Lloyd reduces per-thread partial sums in arrival order: identical up to fp32 rounding across runs
         np.testing.assert_allclose(c.numpy(), g[f"centres_{K}_{iters}"], rtol=1e-4, atol=1e-5)
+
+
+def test_recheck_neartie_reproduces_the_references_batch64_tuples_on_the_recorded_rows():
+    """generate --recheck_neartie (hard part 1's slow path): the product's own torch-CPU restatement of
+    the reference's op order, run on the 64-row batches index/generate_indices.py:77-79 forms, gives the REFERENCE's
+    batch-64 tuple on every one of the 33 rows of the 1 M x 768-d audit where the canonical order differs (fixture F9, whose
+    `ref64_rows` came from the imported reference in this container).  Like the fixture, the outcome belongs to this
+    host's BLAS: the test skips itself where the two rows the reference itself computes differently at batch 4096 vs 64
+    do not reproduce (another CPU / MKL build) -- "parity unpinned across hosts", DESIGN.md section 2.1."""
+    import argparse
+    import hashlib
+    import lcrec_amd
+    from lcrec_amd import generate_indices as gen
+    f = np.load(os.path.join(GOLD, "f9_neartie_c3.npz"))
+    n, in_dim = gi.NEARTIE_CASES["c3"]
+    x = gi.neartie_items(n, in_dim)
+    if hashlib.sha256(x[:65536].tobytes()).hexdigest() != str(f["sha_x_head"]):
+        pytest.skip("numpy's PCG64 float32 normal stream differs from the fixture's")
+    dims, Ws, bs = gi.neartie_encoder(in_dim)
+    names = gi.state_dict_names(len(Ws), False, 4)
+    sd = {}
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        sd[names["encoder"][l] + ".weight"], sd[names["encoder"][l] + ".bias"] = torch.from_numpy(W), torch.from_numpy(b)
+    for l, c in enumerate(f["codebooks"]):
+        sd[names["codebooks"][l]] = torch.from_numpy(c.copy())
+    rows = f["rows"]
+    args = argparse.Namespace(layers=gi.RUN_SH_LAYERS, bn=False)
+    idx = torch.zeros((n, 4), dtype=torch.int64)
+    idx[rows] = torch.from_numpy(f["oracle_rows"].astype(np.int64))
+    flags = torch.zeros(n, dtype=torch.int32)
+    flags[rows] = 1
+    resid_last = torch.zeros((n, 32))
+    torch.set_num_threads(8)                                    # the thread count of the fixture's run (manifest: cpu_threads)
+    done, changed = gen.recheck_neartie(sd, args, x, idx, resid_last, flags)
+    got, want = idx[rows].numpy(), f["ref64_rows"].astype(np.int64)
+    if not np.array_equal(got, want):
+        pytest.skip(f"{int((got != want).any(1).sum())} of 33 recorded rows come out differently on this host's BLAS "
+                    "(the fixture's tuples are this build container's)")
+    assert done == 33 and changed == int((f["ref64_rows"] != f["oracle_rows"]).any(1).sum())
+    early = (f["ref64_rows"][:, :3] != f["oracle_rows"][:, :3]).any(1)
+    assert bool((resid_last[rows[early]].abs().sum(1) > 0).all()) and float(resid_last[rows[~early]].abs().sum()) == 0.0
