@@ -134,6 +134,22 @@ __device__ __forceinline__ bool ticket_is_last(unsigned *ticket, unsigned workgr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return true;
 }
+// The same in two halves, for a caller with useful work to do while the add is in flight (the GEMM epilogue: the add's
+// round trip through the fabric -- a microsecond or two -- passes under the tile's stores): ticket_take() after the
+// hand-over stores have been waited for, ticket_finish() on its result when the answer is needed.
+__device__ __forceinline__ unsigned ticket_take(unsigned *ticket)
+{
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ticket_finish(unsigned *ticket, unsigned taken, unsigned workgroups)
+{
+    if (taken + 1u != workgroups) return false;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return true;
+}
+
 // Sum of `count` handed-over partials (element b at base[b * stride]) in index order, by ONE wave: the lanes fetch them side by
 // side (a chain of dependent agent-scope loads would cost a memory round trip each), the additions then run in order over
 // shuffled-in values -- ((p0 + p1) + p2) + ..., the bits of a sequential loop.  count <= 64 * HANDOFF_MAX_PER_LANE; every lane

@@ -698,21 +698,14 @@ __device__ __forceinline__ void linear_tile_body(
     LCREC_GMARK(2);
     // epilogue (every wave passed the loop's last barrier after its final LDS operand read, so the
     // activation tile's LDS can be reused: 32 rows per wave)
-    float *stg = As + wave * 32 * LDK;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * TM * 32 + i * 32, M, n0 + wn * TN * 32 + j * 32, N, bias,
-                             bn_scale, bn_shift, relu);
-    LCREC_GMARK(3);
+    // ---- STATS, first half (before the tile's stores): batch statistics of t = acc + bias, per column (see TileExtras).  LDS: the
+    // second K-tile buffer, which nobody reads any more (the stores' staging patches are the first buffer).
+    constexpr int RB = BM / 32;                           // 32-row blocks of the tile
+    float *piv = smem + BUF;                              // [BN]  the tile's first row
+    float *red = piv + BN;                                // [RB][BN][2]
+    int *last_sh = reinterpret_cast<int *>(red + RB * BN * 2);
+    unsigned taken = 0;
     if constexpr (STATS) {
-        // ---- batch statistics of t = acc + bias, per column (see TileExtras).  LDS: the second K-tile buffer, which nobody
-        // reads any more (the epilogue's staging patches are the first buffer).
-        constexpr int RB = BM / 32;                       // 32-row blocks of the tile
-        float *piv = smem + BUF;                          // [BN]  the tile's first row
-        float *red = piv + BN;                            // [RB][BN][2]
-        int *last_sh = reinterpret_cast<int *>(red + RB * BN * 2);
         const int c = lane & 31, h = lane >> 5;
         float bj[TN];
 #pragma unroll
@@ -757,8 +750,19 @@ __device__ __forceinline__ void linear_tile_body(
             handoff_put(rec + 2 * (size_t)N, s2);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave's records have reached memory ...
-        __syncthreads();                                   // ... before ONE thread takes the strip's ticket
-        if (tid == 0) *last_sh = ticket_is_last(ex.tickets + bn, (unsigned)bm_blocks) ? 1 : 0;
+        __syncthreads();                                   // ... before ONE thread takes the strip's ticket -- whose round trip
+        if (tid == 0) taken = ticket_take(ex.tickets + bn);   // through the fabric then passes under the tile's stores below
+    }
+    float *stg = As + wave * 32 * LDK;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            store_tile_32x32(acc[i][j], stg, lane, C, m0 + wm * TM * 32 + i * 32, M, n0 + wn * TN * 32 + j * 32, N, bias,
+                             bn_scale, bn_shift, relu);
+    LCREC_GMARK(3);
+    if constexpr (STATS) {
+        if (tid == 0) *last_sh = ticket_finish(ex.tickets + bn, taken, (unsigned)bm_blocks) ? 1 : 0;
         __syncthreads();
         if (*last_sh) {
             // the strip's last tile (uniform over the workgroup): merge the row tiles' (n_T, mean_T, M2_T) in tile order -- the same

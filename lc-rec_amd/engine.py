@@ -55,8 +55,10 @@ class TrainEngine:
         dp_graph: "on" captures the data-parallel step with its RCCL collectives; "off" launches the same line eagerly;
         "auto" = on for a one-rank group (run in the GPU suite), off for more ranks -- UNVERIFIED on more than one GPU."""
         self.model = model
-        # BatchNorm folded into the GEMMs on either side of it (lcrec_linear_bn_forward); LCREC_FUSE_BN=0: the separate kernels
-        self.fuse_bn = (__import__("os").environ.get("LCREC_FUSE_BN", "1") != "0") if fuse_bn is None else bool(fuse_bn)
+        # BatchNorm folded into the GEMMs on either side of it (lcrec_linear_bn_forward: 56 launches per step instead of 68).
+        # OFF by default: measured slower on MI355X (1.28 vs 1.18 ms per step at the run.sh shape) -- a hand-over between
+        # workgroups inside a launch costs as much as the launch it saves (DESIGN.md section 4.5).  LCREC_FUSE_BN=1 turns it on.
+        self.fuse_bn = (__import__("os").environ.get("LCREC_FUSE_BN", "0") == "1") if fuse_bn is None else bool(fuse_bn)
         self.dist = dist if (dist is not None and dist.enabled) else None
         if self.dist is not None:
             import torch.distributed as tdist

@@ -481,7 +481,7 @@ def _run_sh_model(hip, g):
     return model.to(DEV).train(), torch.from_numpy(x).to(DEV)
 
 
-@pytest.mark.parametrize("path", ["engine", "autograd"])
+@pytest.mark.parametrize("path", ["engine", "engine-fused-bn", "autograd"])
 def test_run_sh_step_gradients_against_the_fp64_reference(hip, path):
     """F11: the step index/run.sh actually trains (768 -> 2048-...-64 -> 32, BatchNorm, 4 x 256 codes, Sinkhorn on the last
     level, batch 1024; trainer.py:111-120, layers.py:19-30) against the imported reference run in fp64, tensor by tensor.
@@ -515,7 +515,8 @@ def test_run_sh_step_gradients_against_the_fp64_reference(hip, path):
         judge(grads, [loss.item(), recon.item(), rq_loss.item(), float(norm)], idx.cpu().numpy(), "autograd path")
         return
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
-    eng = TrainEngine(model, opt, "linear", 2, 10)
+    # "engine-fused-bn": BatchNorm folded into the GEMMs on either side of it (lcrec_linear_bn_forward; opt-in, see engine.py)
+    eng = TrainEngine(model, opt, "linear", 2, 10, fuse_bn=path == "engine-fused-bn")
     before = eng.flat_p.clone()
     for step, what in enumerate(("engine, eager step", "engine, captured step")):
         eng.step(x)
