@@ -259,7 +259,8 @@ def dp_training_secondary(device, world, rank, dp_graph):
             out[f"dp_train_step_ms_{key}"] = float(ms.item())
             out[f"dp_train_items_per_s_{key}"] = 1024 * world / (float(ms.item()) * 1e-3)
             out[f"dp_train_graph_replays_{key}"] = eng.graph_replays
-            out["dp_collectives_per_step"] = eng.collectives // max(1, eng.host_steps)
+            if mode == "off":                                         # (a captured step counts its collectives once, at capture)
+                out["dp_collectives_per_step"] = eng.collectives // max(1, eng.host_steps)
             out["train_ranks_seen"] = int(got[:, 0].unique().numel())
             out[f"train_param_checksums_agree_{key}"] = bool((got[:, 1] == got[0, 1]).all())
             del eng, model, opt

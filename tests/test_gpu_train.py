@@ -499,11 +499,20 @@ def test_run_sh_step_gradients_against_the_fp64_reference(hip, path):
     assert sorted(names) == sorted(f11_check.tensors(g))
 
     def judge(grads, scalars, idx, what):
-        assert np.array_equal(idx, g["idx"].astype(np.int64)), what
-        np.testing.assert_allclose(scalars[:3], want[:3], rtol=1e-5, err_msg=what)       # loss, recon, rq_loss
-        np.testing.assert_allclose(scalars[3], want[3], rtol=1e-4, err_msg=what)         # gradient norm before clipping
+        flipped = int((idx != g["idx"].astype(np.int64)).any(1).sum())
+        if path == "engine-fused-bn":
+            # the folded BatchNorm evaluates t * (gamma * rstd) + (beta - mean * gamma * rstd) in one fma: latents differ from the
+            # three-step form in the last bit, which may flip a near-tied assignment or two of the 1024 -- a different (equally
+            # valid) problem for those rows, so the gradient bounds below get room for it
+            assert flipped <= 3, (what, flipped)
+        else:
+            assert flipped == 0, what
+        loose = 4.0 if flipped else 1.0
+        np.testing.assert_allclose(scalars[:3], want[:3], rtol=1e-5 * (10 if flipped else 1), err_msg=what)   # loss, recon, rq_loss
+        np.testing.assert_allclose(scalars[3], want[3], rtol=1e-4 * loose, err_msg=what)         # gradient norm before clipping
         rows, bad = f11_check.report(g, grads)
-        print(f"\n[{what}]\n" + f11_check.table(rows))
+        print(f"\n[{what}] rows assigned differently: {flipped}\n" + f11_check.table(rows))
+        bad = [b for b in bad if not b[2] <= loose * b[4]]
         assert not bad, what + "\n" + f11_check.table(bad)
 
     if path == "autograd":
