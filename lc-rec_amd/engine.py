@@ -422,6 +422,12 @@ class TrainEngine:
         for q in self.ema_levels:
             q.step_count += 1
 
+    def release(self):
+        """Drop the captured graphs (and their private memory pools) now, while the runtime is fully alive, rather than leaving
+        them to interpreter teardown; the next step at a batch size captures again."""
+        torch.cuda.synchronize(self.device)
+        self._graphs.clear()
+
     def begin_epoch(self):
         self.sums.zero_()
 

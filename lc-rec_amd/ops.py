@@ -147,8 +147,16 @@ def release_contexts():
             pass
 
 
+def _forget_contexts_at_exit():
+    """Interpreter exit: drop the handles WITHOUT calling into the library.  lcrec_context_destroy synchronises and destroys
+    streams; at exit the HIP runtime (and a profiler's preloaded tool library) is tearing down underneath it, and a profiled run
+    was seen not to return from its exit handlers (tools/prof_train.sh).  Process teardown reclaims streams, events and pinned
+    memory anyway; release_contexts() remains the explicit, orderly way while the process lives."""
+    _contexts.clear()
+
+
 import atexit  # noqa: E402
-atexit.register(release_contexts)
+atexit.register(_forget_contexts_at_exit)
 
 
 def _audit_buffers(audit, tie_tau, n, L, dev):

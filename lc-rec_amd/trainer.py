@@ -375,4 +375,6 @@ class Trainer(object):
                 ckpt_path = self._save_checkpoint(epoch_idx, collision_rate=collision_rate)
                 if self._is_main():
                     self.keeper.add(collision_rate, ckpt_path)
+        if self.engine is not None:
+            self.engine.release()            # captured graphs go now, in order, not at interpreter teardown
         return self.best_loss, self.best_collision_rate

@@ -1,7 +1,10 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the training step (Trainer._train_epoch through the captured hipGraph) -> gpurun_out/<name>/tr_results.db,
-# then per-kernel statistics as CSV.  The profiled python sometimes fails to exit after rocprofv3 has written its database
-# (seen once: 7 minutes until the silence watchdog), so it runs under `timeout`; the database is complete by then.
+# then per-kernel statistics as CSV.  Round 2 saw the profiled python once fail to exit after rocprofv3 had written its database
+# (7 minutes until the silence watchdog).  The library made GPU calls from an atexit handler then (lcrec_context_destroy:
+# hipStreamSynchronize / hipStreamDestroy while the runtime and the profiler's tool library were tearing down); since round 3 it
+# makes none at exit (ops._forget_contexts_at_exit) and Trainer.fit releases its graphs itself.  Not seen again in this round's
+# six profiled runs; the `timeout` stays as a backstop.
 #   tools/prof_train.sh NAME [train_probe args...]
 set -u
 name=$1; shift
