@@ -132,6 +132,20 @@ def test_generate_reproduces_reference_index_json_bytes(hip, tmp_path):
     want = bytes(g["json_text"])
     got = open(out, "rb").read()
     assert got == want, "index.json differs from the reference's bytes"
+    # --recheck_neartie: the flagged items go through the reference's torch CPU op order on their batch-64 neighbours.  On this
+    # toy every flagged item already carries the reference's tuple, so -- on a host whose BLAS rounds like the fixture's --
+    # nothing changes; on another host at most the flagged items may (the slow path follows the HOST's
+    # arithmetic, as a CPU run of the reference there would).
+    out2 = str(tmp_path / "Toy.recheck.index.json")
+    stats2 = gen.generate(ckpt, out2, device="cuda:0", verbose=False, recheck=True)
+    assert stats2["rechecked_items"] == stats2["neartie_items"] == stats["neartie_items"]
+    assert 0 <= stats2["recheck_changed"] <= stats2["rechecked_items"]
+    a, b = json.loads(got), json.load(open(out2))
+    differing = [k for k in a if a[k] != b[k]]
+    if stats2["recheck_changed"] == 0:
+        assert open(out2, "rb").read() == want
+    else:
+        assert list(b) == list(a) and len(differing) <= 20 * max(1, stats2["recheck_changed"])     # (rounds propagate a change within its groups)
 
 
 @pytest.mark.parametrize("strict", [False, True])
