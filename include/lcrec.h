@@ -24,7 +24,21 @@
  *     (the one documented host wait: lcrec_sinkhorn_assign with many groups and a
  *     NULL context);
  *   - no global mutable state apart from the diagnostic trace log; a context is used
- *     by one host thread at a time (one process per GPU needs no locking);
+ *     by one host thread at a time (one process per GPU needs no locking).  The library
+ *     reads a handful of environment variables ONCE per process, on the first call that
+ *     consults them (function-local statics): they select between kernels that compute
+ *     the same bits and exist for A/B measurements, not for configuration --
+ *       LCREC_GEMM_PP, LCREC_GEMM_PP3, LCREC_GEMM_FAST, LCREC_GEMM_SMALL, LCREC_GEMM_TUNE
+ *                                  which tiling / kernel form lcrec_linear_forward takes
+ *       LCREC_GEMM_SPLITK           cap on the K-runs of the weight gradient (changes S of
+ *                                  lcrec_linear_backward_splits, hence its documented sum)
+ *       LCREC_RQ_SPLIT              the batch-sized form of lcrec_rq_assign
+ *       LCREC_SINKHORN_SCALING, LCREC_SINKHORN_PERSISTENT, LCREC_SK_RW, LCREC_SK_BLOCKS
+ *                                  which batch-sized Sinkhorn solver runs (assignments may
+ *                                  differ only inside the 1e-9 margin stated at the call)
+ *       LCREC_STRIP_COLS            strip width of the BatchNorm column reductions
+ *     A deployment sets none of them; being process-global they are outside the
+ *     per-call / per-context contract above;
  *   - return 0 on success, a negative LCREC_E* code otherwise; the message for
  *     the calling thread's last error is lcrec_last_error(); nothing throws;
  *   - arithmetic contract: every contraction is one fp32 fused-multiply-add
