@@ -27,7 +27,7 @@ const char *const kKernelNames[K_COUNT] = {"linear_fwd_128x128", "linear_fwd_128
                                            "sinkhorn_small", "rq_apply_level", "code_stats", "ema_update",
                                            "collision_groups", "linear_fwd_pp_256x128", "linear_fwd_64x64", "sinkhorn_slab",
                                            "sinkhorn_tiny", "bn_relu_forward", "bn_relu_backward", "relu_bias_backward",
-                                           "recon_loss_grad", "grad_norm_clip", "adamw_step"};
+                                           "recon_loss_grad", "grad_norm_clip", "adamw_step", "linear_fwd_32x64"};
 
 struct TraceRec { int kernel; hipEvent_t start, stop; };
 static std::mutex g_trace_mu;

@@ -31,7 +31,7 @@ inline int check_launch(const char *what)
 enum KernelId { K_LINEAR_128x128 = 0, K_LINEAR_128x64, K_LINEAR_128x32, K_RQ_ASSIGN, K_RQ_SSE_FINALIZE,
                 K_VQ_DISTANCE, K_SINKHORN, K_SINKHORN_SMALL, K_APPLY_LEVEL, K_CODE_STATS, K_EMA_UPDATE, K_COLLISION,
                 K_LINEAR_PP, K_LINEAR_64x64, K_SINKHORN_SLAB, K_SINKHORN_TINY, K_BN_FWD, K_BN_BWD, K_RELU_BIAS_BWD, K_LOSS,
-                K_GRAD_NORM, K_ADAMW, K_COUNT };
+                K_GRAD_NORM, K_ADAMW, K_LINEAR_32x64, K_COUNT };
 extern const char *const kKernelNames[K_COUNT];
 bool trace_on();
 void trace_begin(int kernel, hipStream_t stream);

@@ -1513,6 +1513,191 @@ __global__ __launch_bounds__(512) void linear_fwd_pp3_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small-tile kernel for launches that 64 x 64 tiles cannot fill the chip with (a training step's layers, the row tail of a
+// Games-sized launch): 32 x 64 tiles on v_mfma_f32_16x16x4_f32.
+//
+// Why another instruction.  At batch 1024 a 1024-column layer is 4096 outputs per CU: with 32 x 32 x 2 tiles exactly one
+// accumulator per SIMD, one wave per SIMD, and nothing to run under that wave's LDS round trips and barriers (the 64 x 64
+// kernel's MFMA pipe is busy 0.69-0.79 of such a launch, profiles/r03_pmc_mfma.txt).  v_mfma_f32_16x16x4_f32 has the same peak
+// (2048 flop / 32 cycles) on a quarter of the outputs, so the same work makes TWO waves per SIMD (two workgroups per CU), each
+// with two independent 16 x 16 accumulators; and its dependent chain is 40 cycles per 4 k against 64 per 2 k, which is what
+// bounds a launch of few tiles (a row tail's serial K loop).  It keeps the arithmetic contract: its four k-products are ONE fp32
+// fma chain, k ascending, onto the accumulator -- measured bit for bit against fmaf on gfx950 (tools/mfma16_probe.hip) -- so a
+// 16 x 16 tile fed k = 4s .. 4s+3 for s ascending reproduces oracle/lcrec_oracle.c like the big tiles do.
+//
+// A workgroup of four waves covers 32 x 64: wave (wm, wn) rows 16 wm .., columns 32 wn .. (two 16 x 16 blocks).  Same K-tile
+// pipeline as the 64 x 64 kernel: two LDS buffers, operand fragments of K-tile kt+1 read into a second register set under
+// K-tile kt's 16 MFMAs, K-tile kt+2 stored into the buffer kt was read from, a ring of register sets for the global prefetch,
+// every LDS / memory instruction in an MFMA gap of its own, one barrier per K-tile.
+// LDS image of a row-major operand tile: rows of 32 k padded to 36 floats, k at position (k % 4) * 8 + k / 4, so that lane
+// (r = lane % 16, q = lane / 16) finds its operands of all eight MFMAs of the K-tile -- k = q, 4 + q, ..., 28 + q -- in 8
+// consecutive floats: two ds_read_b128 (conflict-free: 36 = 4 mod 32).  A k-major W (the dX product reads W [out][in] as
+// [K][N]) keeps a k-major image [32 k][72]: 16-byte stores as loaded, 4-byte fragment reads.
+constexpr int S16_BM = 32, S16_BN = 64, S16_LDN = 72, S16_RING = 4;
+
+template <bool TB>
+__global__ __launch_bounds__(256) void linear_s16_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, const float *__restrict__ bn_scale,
+                                                         const float *__restrict__ bn_shift, float *__restrict__ C, int64_t M, int N,
+                                                         int K, int relu, int bn_blocks)
+{
+    constexpr int A_FLOATS = S16_BM * LDK, W_FLOATS = TB ? BK * S16_LDN : S16_BN * LDK, BUF = A_FLOATS + W_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q = lane >> 4;
+    const int64_t bm = blockIdx.x / bn_blocks;
+    const int bn = blockIdx.x % bn_blocks;
+    const int64_t m0 = bm * S16_BM;
+    const int n0 = bn * S16_BN;
+    const int nk = K / BK;                                    // K % 32 == 0 (the launcher's condition)
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A, m0, M, S16_BM, K);
+    const __amdgpu_buffer_rsrc_t w_rsrc = TB ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, (int)((int64_t)K * N * 4), 0x00020000)
+                                             : tile_rsrc(W, n0, N, S16_BN, K);
+    struct Regs { f32x4 a, w[2]; };
+    struct Frag { f32x4 a[2], b[2][2]; };                     // [k half][...]: MFMAs s = 0..3 use half 0, s = 4..7 half 1
+    constexpr unsigned SOFF_OUT = 0x7fffff00u;
+    const int arow = tid >> 3, akq = tid & 7;                 // A: 32 rows x 8 float4; row-major W: rows arow, arow + 32
+    const int wkk = tid >> 4, wn4 = tid & 15;                 // k-major W: 32 k x 16 float4, k = wkk, wkk + 16
+    const bool w_in = !TB || n0 + wn4 * 4 < N;
+    const int a_vo = (arow * K + akq * 4) * 4;
+    const int w_vo0 = TB ? (w_in ? (int)(((int64_t)wkk * N + n0 + wn4 * 4) * 4) : 0x7fffff00) : a_vo;
+    const int w_vo1 = TB ? (w_in ? (int)(((int64_t)(wkk + 16) * N + n0 + wn4 * 4) * 4) : 0x7fffff00) : a_vo + 32 * K * 4;
+    // one of the three 16-byte loads of a K-tile (piece 0: A, 1 / 2: W); a K-tile past the end is "loaded" from beyond the
+    // descriptor's extent: zeros, no memory access, no branch for the waitcnt bookkeeping to merge
+    auto load_piece = [&](Regs &g, int kt, bool live, auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value;
+        const unsigned so = live ? (TB && piece > 0 ? (unsigned)((int64_t)kt * BK * N * 4) : (unsigned)(kt * (BK * 4))) : SOFF_OUT;
+        if constexpr (piece == 0) g.a = buffer_load_f32x4(a_rsrc, a_vo, (int)so);
+        else if constexpr (piece == 1) g.w[0] = buffer_load_f32x4(w_rsrc, w_vo0, (int)so);
+        else g.w[1] = buffer_load_f32x4(w_rsrc, w_vo1, (int)so);
+    };
+    const uint32_t a_st = (uint32_t)((arow * LDK + akq) * 4);                       // k = 4 akq + i -> position i * 8 + akq
+    const uint32_t wk_st = (uint32_t)((A_FLOATS + wkk * S16_LDN + wn4 * 4) * 4);
+    // six LDS store instructions per K-tile (row-major: ds_write2_b32 pairs; k-major W: ds_write_b128): piece 0, 1 = A
+    auto store_piece = [&](const Regs &g, int buf, auto piece_c) {
+        constexpr int piece = decltype(piece_c)::value;
+        const uint32_t base = lds_addr(smem) + (uint32_t)(buf * BUF * 4);
+        if constexpr (piece < 2) {
+            const uint32_t ad = base + a_st + piece * 64;
+            asm volatile("ds_write2_b32 %0, %1, %2 offset1:8" ::"v"(ad), "v"(g.a[2 * piece]), "v"(g.a[2 * piece + 1]) : "memory");
+        } else if constexpr (TB) {
+            const uint32_t ad = base + wk_st;                 // (named here: clang does not capture a variable first used inside the nested constexpr-if)
+            if constexpr (piece < 4) asm volatile("ds_write_b128 %0, %1" ::"v"(ad + (uint32_t)((piece - 2) * 16 * S16_LDN * 4)), "v"(g.w[piece - 2]) : "memory");
+        } else {
+            constexpr int j = (piece - 2) >> 1, h = (piece - 2) & 1;
+            const uint32_t ad = base + (uint32_t)(A_FLOATS * 4) + a_st + (uint32_t)(j * 32 * LDK * 4) + h * 64;
+            asm volatile("ds_write2_b32 %0, %1, %2 offset1:8" ::"v"(ad), "v"(g.w[j][2 * h]), "v"(g.w[j][2 * h + 1]) : "memory");
+        }
+    };
+    // six (row-major W) fragment reads of 16 bytes per K-tile: slot 0, 1 = A halves; 2 .. 5 = W block cb = (slot - 2) / 2, half
+    const float *a_fr = smem + (16 * wm + r16) * LDK + q * 8;
+    const float *w_fr = smem + A_FLOATS + (32 * wn + r16) * LDK + q * 8;
+    const float *wk_fr = smem + A_FLOATS + q * S16_LDN + 32 * wn + r16;
+    auto frag_read = [&](Frag &f, int buf, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        if constexpr (slot < 2) {
+            f.a[slot] = *reinterpret_cast<const f32x4 *>(a_fr + buf * BUF + slot * 4);
+        } else {
+            constexpr int cb = (slot - 2) >> 1, h = (slot - 2) & 1;
+            if constexpr (TB) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) f.b[h][cb][s] = wk_fr[buf * BUF + (4 * s + 16 * h) * S16_LDN + 16 * cb];
+            } else {
+                f.b[h][cb] = *reinterpret_cast<const f32x4 *>(w_fr + buf * BUF + cb * 16 * LDK + h * 4);
+            }
+        }
+    };
+
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    Frag fa, fb;
+    Regs ring[S16_RING];
+    if (nk > 0) {
+        static_for<S16_RING>([&](auto j_c) {
+            constexpr int j = decltype(j_c)::value;
+            static_for<3>([&](auto p_c) { load_piece(ring[j], j, j < nk, p_c); });
+        });
+        static_for<6>([&](auto p_c) { store_piece(ring[0], 0, p_c); });
+        static_for<6>([&](auto p_c) { store_piece(ring[1], 1, p_c); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<3>([&](auto p_c) { load_piece(ring[0], S16_RING, S16_RING < nk, p_c); });
+        __syncthreads();
+        static_for<6>([&](auto s_c) { frag_read(fa, 0, s_c); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                      // iteration 0 stores K-tile 2 into buffer 0
+    }
+    // iteration kt: MFMAs of kt from `fc`; fragments of kt+1 from buffer (kt+1)&1 into `fn`; K-tile kt+2 (ring set (kt+2) % RING)
+    // into buffer kt&1; K-tile kt+RING+1 loaded into set (kt+1) % RING
+    auto k_tile = [&](int kt, const Frag &fc, Frag &fn, Regs &r_free, const Regs &r_next, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        const bool live = kt + S16_RING + 1 < nk;
+        static_for<16>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value, cb = s & 1, ks = s >> 1, h = ks >> 2, sq = ks & 3;
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fc.a[h][sq], fc.b[h][cb][sq], acc[cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s < 6) frag_read(fn, cur ^ 1, IntC<s>{});
+            if constexpr (s >= 6 && s < 9) load_piece(r_free, kt + S16_RING + 1, live, IntC<s - 6>{});
+            if constexpr (s >= 9 && s < 15) store_piece(r_next, cur, IntC<s - 9>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += S16_RING) {
+        static_for<S16_RING>([&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            if (u == 0 || kt + u < nk) {
+                if constexpr (u % 2 == 0) k_tile(kt + u, fa, fb, ring[(u + 1) % S16_RING], ring[(u + 2) % S16_RING], IntC<0>{});
+                else k_tile(kt + u, fb, fa, ring[(u + 1) % S16_RING], ring[(u + 2) % S16_RING], IntC<1>{});
+            }
+        });
+    }
+
+    // epilogue: lane holds rows 4 q + r (r = 0..3) of column r16 of each 16 x 16 block
+    const bool has_bn = bn_scale != nullptr;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = n0 + 32 * wn + 16 * cb + r16;
+        if (col >= N) continue;
+        const float bj = bias ? bias[col] : 0.f;
+        const float sc = has_bn ? bn_scale[col] : 1.f, sh = has_bn ? bn_shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = m0 + 16 * wm + 4 * q + r;
+            if (row >= M) continue;
+            float t = acc[cb][r] + bj;
+            if (has_bn) t = __builtin_fmaf(t, sc, sh);
+            if (relu) t = t > 0.f ? t : 0.f;
+            C[row * (int64_t)N + col] = t;
+        }
+    }
+}
+
+static int launch_s16(const float *A, const float *W, const float *b, const float *sc, const float *sh, int relu, float *C, int64_t M,
+                      int N, int K, bool kmajor_w, hipStream_t stream)
+{
+    const int64_t bm_blocks = (M + S16_BM - 1) / S16_BM;
+    const int bn_blocks = (N + S16_BN - 1) / S16_BN;
+    const int64_t grid = bm_blocks * bn_blocks;
+    if (grid > 0x7fffffffLL) return fail(LCREC_EINVAL, "linear (32 x 64 tiles): grid too large");
+    TraceScope trace(K_LINEAR_32x64, stream);
+    if (kmajor_w) hipLaunchKernelGGL(linear_s16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, A, W, b, sc, sh, C, M, N, K, relu, bn_blocks);
+    else hipLaunchKernelGGL(linear_s16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, A, W, b, sc, sh, C, M, N, K, relu, bn_blocks);
+    return check_launch("linear_s16_kernel");
+}
+
+// Which launches take the 32 x 64 tiles: K a multiple of 32, and 64 x 64 tiles would leave the chip under-filled -- at most
+// LCREC_GEMM_S16_TILES (default below) of them.  LCREC_GEMM_S16=0 never, =1 whenever the shape allows (tuning).
+static bool use_s16_tiles(int64_t M, int N, int K)
+{
+    static const int mode = [] { const char *e = getenv("LCREC_GEMM_S16"); return e ? atoi(e) : -1; }();
+    static const int limit = [] { const char *e = getenv("LCREC_GEMM_S16_TILES"); return e ? atoi(e) : 128; }();
+    if (mode == 0 || K % BK != 0 || K < BK || N % 4 != 0 || (int64_t)K * 4 * (M + 64) >= (1ll << 31) || (int64_t)K * N * 4 >= (1ll << 31)) return false;
+    if (mode == 1) return true;
+    return ((M + 63) / 64) * ((N + 63) / 64) <= limit;
+}
+
 static int launch_pp2(dim3 grid, hipStream_t stream, const float *x, const float *W, const float *b, const float *sc,
                       const float *sh, float *y, int64_t n, int out_dim, int in_dim, int relu, int bn_blocks, int bm_blocks,
                       int xcd_order)
@@ -1647,6 +1832,10 @@ template <bool TA>
 static int gemm_kmajor(const float *A, const float *B, int64_t M, int N, int K, float *C, int splits, float *partial,
                        hipStream_t stream)
 {
+    if constexpr (!TA) {
+        if (splits <= 1 && use_s16_tiles(M, N, K))          // dX of an under-filled launch: the 32 x 64 tiles
+            return launch_s16(A, B, nullptr, nullptr, nullptr, 0, C, M, N, K, true, stream);
+    }
     switch (kmajor_shape(M, N)) {
     case 0: return launch_kmajor<2, 2, 1, 1, TA>(A, B, M, N, K, C, splits, partial, stream);
     case 1: return launch_kmajor<2, 2, 2, 2, TA>(A, B, M, N, K, C, splits, partial, stream);
@@ -1901,6 +2090,9 @@ int linear_forward(const float *x, int64_t n, int in_dim, const float *W, const 
     }
     const bool use_pp = out_dim > 64 && pp_ok && (pp == 1 || (pp == -1 && pp_fits));
     if (use_pp) return launch_linear_pp(x, n, in_dim, W, b, bn_scale, bn_shift, relu, out_dim, y, pp_tune, stream);
+    // launches that 64 x 64 tiles cannot fill the chip with: 32 x 64 tiles on the 16 x 16 x 4 MFMA (linear_s16_kernel)
+    if (use_s16_tiles(n, out_dim, in_dim))
+        return launch_s16(x, W, b, bn_scale, bn_shift, relu, y, n, out_dim, in_dim, false, stream);
     if (out_dim > 64) {
         // batch-sized problems (a training step has 1-2 k rows): 128 x 128 tiles would leave most CUs idle,
         // so launches with fewer than two tiles per CU use 64 x 64 tiles (4x the workgroups)

@@ -27,6 +27,11 @@ def _rs(seed):
     (8192, 256, 2048, True, True),       # BatchNorm epilogue
     (16000, 192, 2048, True, False),     # six K-tiles, last row panel half empty
     (8200, 384, 4096, False, False),     # 33 row panels over 8 XCDs (holes in the XCD-aware tile order), no ReLU
+    # launches of at most 128 tiles of 64 x 64 (K % 32 == 0) take the 32 x 64 tiles on v_mfma_f32_16x16x4_f32:
+    (1024, 1024, 512, True, True),       # a training step's layer: 128 tiles -> 256 workgroups of the small kernel
+    (475, 2048, 1024, True, False),      # the row tail of a Games-sized launch: ragged rows (475 = 14 x 32 + 27)
+    (1024, 512, 252, False, True),       # ragged columns: the last column tile reads weight rows past N as zeros
+    (31, 32, 4, False, False),           # one K-tile, one partial tile
 ])
 def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     rs = _rs(n + k + out)
@@ -45,12 +50,16 @@ def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
     assert ("linear_fwd_pp_256x128" in trace) == (n >= 8192 and k % 32 == 0), trace      # the intended kernel ran
+    small = k % 32 == 0 and out % 4 == 0 and -(-n // 64) * -(-out // 64) <= 128 and n < 8192
+    assert ("linear_fwd_32x64" in trace) == small, trace
 
 
 @pytest.mark.parametrize("n,k,out", [(2048, 768, 2048), (475, 128, 64), (1000, 64, 32), (300, 2048, 1024), (77, 32, 128),
                                      (2048, 36, 96), (1, 64, 32),
                                      (1024, 1024, 2048),      # dW [2048, 1024]: 64 x 128 tiles, both operands k-major
-                                     (1000, 2048, 512)])      # dX [1000, 2048]: 64 x 128 tiles, ragged rows
+                                     (1000, 2048, 512),       # dX [1000, 2048]: 64 x 128 tiles, ragged rows
+                                     (1024, 512, 1024),       # dX [1024, 512] over K = 1024: 128 tiles -> the 32 x 64 tiles, k-major W
+                                     (475, 252, 96)])         # ... ragged rows and columns (252 = 3 x 64 + 60), K = 96
 def test_linear_backward_bit_exact(hip, oracle, n, k, out):
     """lcrec_linear_backward (k-major operand staging, no transposed copies) against the oracle's restatement
     on explicitly transposed operands: gx = gy W one fma chain per output; gw = gy^T x as the ordered sum of
