@@ -50,8 +50,9 @@ def test_linear_bit_exact(hip, oracle, n, k, out, relu, bn):
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
     assert ("linear_fwd_pp_256x128" in trace) == (n >= 8192 and k % 32 == 0), trace      # the intended kernel ran
-    small = k % 32 == 0 and out % 4 == 0 and -(-n // 64) * -(-out // 64) <= 128 and n < 8192
-    assert ("linear_fwd_32x64" in trace) == small, trace
+    if n < 8192:         # (a launch cut into whole rounds for the ping-pong kernel hands its row tail on: that tail may be small too)
+        small = k % 32 == 0 and out % 4 == 0 and -(-n // 64) * -(-out // 64) <= 128
+        assert ("linear_fwd_32x64" in trace) == small, trace
 
 
 @pytest.mark.parametrize("n,k,out", [(2048, 768, 2048), (475, 128, 64), (1000, 64, 32), (300, 2048, 1024), (77, 32, 128),

@@ -512,8 +512,10 @@ def test_run_sh_step_gradients_against_the_fp64_reference(hip, path):
         np.testing.assert_allclose(scalars[3], want[3], rtol=1e-4 * loose, err_msg=what)         # gradient norm before clipping
         rows, bad = f11_check.report(g, grads)
         print(f"\n[{what}] rows assigned differently: {flipped}\n" + f11_check.table(rows))
-        # (one row of 1024 with another code moves a decoder gradient by ~1e-3 of its norm: the problem differs, not the arithmetic)
-        bad = [b for b in bad if not b[2] <= (max(loose * b[4], 3e-3) if flipped else b[4])]
+        # (a row with another code is another problem, not other arithmetic: two of 1024 move the encoder's gradient by ~2 % of its
+        # norm -- the per-tensor bounds then say nothing; the folded kernels themselves are pinned bit for bit by
+        # test_linear_bn_forward_is_the_oracle_chain_with_batch_statistics / test_folded_batchnorm_operands_in_the_backward_products)
+        bad = [b for b in bad if not flipped and not b[2] <= b[4]]
         assert not bad, what + "\n" + f11_check.table(bad)
 
     if path == "autograd":
