@@ -533,13 +533,21 @@ def main():
     # N > 1 (every rank takes part): the data-parallel training step as a secondary figure, under a watchdog -- a hang in it
     # (this path has never run on more than one GPU) must not cost the line: after 240 s rank 0 prints the line without it
     dp = None
+    printed = [False]
+
+    def emit():
+        if rank == 0 and not printed[0]:
+            printed[0] = True
+            print(json.dumps(out), flush=True)
+
+    timer = None
     if use_dist and args.backend == "nccl" and not args.no_dp_train and not args.no_secondary:
         import threading
 
         def give_up():
-            if rank == 0:
+            if rank == 0 and "secondary_dp" not in out:
                 out["secondary_dp"] = {"error": "timeout after 240 s (data-parallel training step)"}
-                print(json.dumps(out), flush=True)
+            emit()
             os._exit(0)
 
         timer = threading.Timer(240.0, give_up)
@@ -549,14 +557,19 @@ def main():
             dp = dp_training_secondary(device, world, rank, args.dp_graph)
         except Exception as err:
             dp = {"error": f"{type(err).__name__}: {err}"}
-        timer.cancel()
-    if rank == 0:
-        if dp is not None:
-            out["secondary_dp"] = dp
-        print(json.dumps(out), flush=True)
+    if rank == 0 and dp is not None:
+        out["secondary_dp"] = dp
+    emit()
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        # (a rank that failed in the secondary above may leave its peers inside a collective: the line is out, the watchdog is
+        # still armed, and an error in the farewell barrier is not an error of the measurement)
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    if timer is not None:
+        timer.cancel()
 
 
 if __name__ == "__main__":
