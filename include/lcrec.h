@@ -28,8 +28,10 @@
  *     reads a handful of environment variables ONCE per process, on the first call that
  *     consults them (function-local statics): they select between kernels that compute
  *     the same bits and exist for A/B measurements, not for configuration --
- *       LCREC_GEMM_PP, LCREC_GEMM_PP3, LCREC_GEMM_FAST, LCREC_GEMM_SMALL, LCREC_GEMM_TUNE
- *                                  which tiling / kernel form lcrec_linear_forward takes
+ *       LCREC_GEMM_PP, LCREC_GEMM_PP3, LCREC_GEMM_FAST, LCREC_GEMM_SMALL, LCREC_GEMM_TUNE,
+ *       LCREC_GEMM_S16, LCREC_GEMM_S16_TILES
+ *                                  which tiling / kernel form lcrec_linear_forward (and the
+ *                                  dX product of lcrec_linear_backward) takes
  *       LCREC_GEMM_SPLITK           cap on the K-runs of the weight gradient (changes S of
  *                                  lcrec_linear_backward_splits, hence its documented sum)
  *       LCREC_RQ_SPLIT              the batch-sized form of lcrec_rq_assign
