@@ -4,6 +4,7 @@
   linear_fwd_pp3   the dominant encoder GEMM: 131 072 rows (one chunk of lcrec_encode_assign) x 768 -> 2048 and x 2048 -> 1024
   rq_assign        1 000 000 latents x 32 through 4 x 256 codes (C3's quantiser pass)
   linear_fwd 64x64 the batch-sized kernel of a training step: 1024 x 2048 -> 1024
+  linear_s16       the 32 x 64-tile kernel (v_mfma_f32_16x16x4_f32) on a launch it is dispatched for: 1024 x 1024 -> 512
 
     python tools/pmc_target.py [reps]
 """
@@ -36,5 +37,9 @@ for _ in range(reps):
 xb = rnd(1024, 2048)
 for _ in range(4 * reps):
     ops.linear_forward(xb, w1, b1, relu=True)
+w2, b2 = rnd(512, 1024) * 0.03, torch.zeros(512, device=dev)
+xc = rnd(1024, 1024)
+for _ in range(4 * reps):
+    ops.linear_forward(xc, w2, b2, relu=True)
 torch.cuda.synchronize()
 print("pmc_target done")

@@ -80,7 +80,8 @@ def pmc(a):
 
 
 MFMA_KERNELS = [("linear_fwd_pp3_kernel", "linear_fwd_pp3 (256x128 ping-pong)"), ("rq_assign_kernel", "rq_assign"),
-                ("linear_fwd_kernel<2, 2, 1, 1", "linear_fwd 64x64 (training step)")]
+                ("linear_fwd_kernel<2, 2, 1, 1", "linear_fwd 64x64 (training step)"),
+                ("linear_s16_kernel", "linear_s16 32x64 on 16x16x4 (training step, under-filled launches)")]
 CUS, SIMDS = 256, 4
 
 
@@ -129,8 +130,10 @@ def mfma(dbs):
             print(f"    MFMA_BUSY / (1024 pipes x duration x 2.4 GHz) = {busy / (CUS * SIMDS * d_ns * 2.4):.3f}")
         n_mfma = avg.get("SQ_INSTS_MFMA")
         if n_mfma and busy:
-            # v_mfma_f32_32x32x2_f32: 32*32*2 multiply-adds = 4096 flop, 64 pipe cycles each (busy / instructions confirms it)
-            print(f"    MFMA instructions {n_mfma:.0f} x 4096 flop / duration = {n_mfma * 4096 / d_ns / 1e3:.1f} TFLOP/s "
+            # v_mfma_f32_32x32x2_f32: 32*32*2 multiply-adds = 4096 flop, 64 pipe cycles each; v_mfma_f32_16x16x4_f32: 2048 flop, 32
+            # cycles (busy / instructions tells which)
+            per = 2048 if busy / n_mfma < 48 else 4096
+            print(f"    MFMA instructions {n_mfma:.0f} x {per} flop / duration = {n_mfma * per / d_ns / 1e3:.1f} TFLOP/s "
                   f"(roof 157.3); busy cycles per instruction {busy / n_mfma:.1f}")
         wc = avg.get("SQ_WAVE_CYCLES")
         if wc:
