@@ -23,7 +23,10 @@ namespace lcrec {
 
 constexpr int CR_THREADS = 1024;  // 16 waves per strip: enough loads in flight to cover HBM/L2 latency from one CU
 constexpr int CR_WAVES = CR_THREADS / 64;
-constexpr int CR_UNROLL = 8;
+#ifndef LCREC_CR_UNROLL
+#define LCREC_CR_UNROLL 8
+#endif
+constexpr int CR_UNROLL = LCREC_CR_UNROLL;
 
 // Strip geometry: COLS columns x RGS = 1024 / COLS row groups; lane l of a wave holds column l % COLS, so a wave spans
 // 64 / COLS consecutive row groups.  Row group g owns rows g, g + RGS, ... (each lane adds its rows in ascending order,
@@ -676,7 +679,8 @@ static int strip_cols(int F)
         while (cols_ > 8 && (int64_t)(n) > (int64_t)CR_MAXR * (CR_THREADS / cols_)) cols_ /= 2;                       \
         /* measured (768-d recipe): at 1024 rows the second pass hits L2 anyway and the cached form is ~1 % slower; at */ \
         /* 2048 rows the narrower strips + cached rows are ~3 % of the step faster                                    */ \
-        const bool cached_ = (int64_t)(n) > 1024 && (int64_t)(n) <= (int64_t)CR_MAXR * (CR_THREADS / cols_);          \
+        static const int cached_min_ = [] { const char *e = getenv("LCREC_BN_CACHED_MIN"); return e ? atoi(e) : 1025; }();   /* tuning */ \
+        const bool cached_ = (int64_t)(n) >= cached_min_ && (int64_t)(n) <= (int64_t)CR_MAXR * (CR_THREADS / cols_);  \
         const dim3 grid_((unsigned)(((F) + cols_ - 1) / cols_));                                                      \
         if (cols_ == 32) { if (cached_) hipLaunchKernelGGL((KERN<32, true>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((KERN<32, false>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); } \
         else if (cols_ == 16) { if (cached_) hipLaunchKernelGGL((KERN<16, true>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((KERN<16, false>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); } \
