@@ -398,7 +398,7 @@ def main():
         neartie_rows = int(got[:, 2].sum())
 
     # Algorithmic flops per GEMM kernel: replay the library's dispatch rule (gemm_f32.hip, linear_forward)
-    # over the chunks lcrec_encode_assign walks (131072 rows each).
+    # over the chunks lcrec_encode_assign walks (lcrec_encode_assign_chunk_rows() each).
     def gemm_pieces(rows, out, k):
         """[(kernel name, rows)] of one Linear launch: the library's dispatch rule (gemm_f32.hip, linear_forward)."""
         if out <= 32:
@@ -427,8 +427,9 @@ def main():
 
     macs_all = sum(dims[l] * dims[l + 1] for l in range(len(dims) - 1)) + sum(E_DIM * k for k in ks)
     flops, alg_bytes = {}, {}
-    for lo in range(0, n, 131072):
-        rows = min(131072, n - lo)
+    chunk = int(lcrec_amd._lib.load().lcrec_encode_assign_chunk_rows())
+    for lo in range(0, n, chunk):
+        rows = min(chunk, n - lo)
         for l in range(len(dims) - 1):
             out = dims[l + 1]
             for kname, part in gemm_pieces(rows, out, dims[l]):

@@ -233,12 +233,14 @@ int lcrec_rq_assign(const float *z, int64_t n, int e, const float *codebooks, co
  *   latent_out device [n][e] or NULL  encoder output
  *   others     as lcrec_rq_assign (margin_out / neartie_out / tie_tau: the near-tie audit of the quantiser)
  *   ctx        NULL, or a context of the current device
- * Items are processed in chunks of 131072.  With a context whose pipelines setting is 2 (opt-in), odd chunks run on
+ * Items are processed in chunks of lcrec_encode_assign_chunk_rows() = 524 288.  With a context whose pipelines setting is 2 (opt-in), odd chunks run on
  * the context's first helper stream, forked from `stream` by an event at entry and joined back into it before
  * the quantiser pass (and on every error exit), so everything is ordered after prior work on `stream` and
  * before later work on it, without any host synchronisation; with ctx == NULL or pipelines == 1 every launch
  * is on `stream`. */
 size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n_layers, const int *K, int L);
+/* rows per chunk of the walk described above (a build constant; results do not depend on it) */
+int64_t lcrec_encode_assign_chunk_rows(void);
 int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers,
                         const float *const *W, const float *const *b,
                         const float *const *bn_scale, const float *const *bn_shift,

@@ -41,6 +41,7 @@ _SIGNATURES = {
                                        _vp, ctypes.c_size_t, _vp, _vp]),
     "lcrec_encode_assign_workspace": (ctypes.c_size_t, [ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                                         ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "lcrec_encode_assign_chunk_rows": (ctypes.c_int64, []),
     "lcrec_encode_assign": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                            ctypes.POINTER(_vp), _vp, ctypes.POINTER(ctypes.c_int), ctypes.c_int,

@@ -52,9 +52,15 @@ void trace_end(hipStream_t stream)
     if (!g_trace.empty()) (void)hipEventRecord(g_trace.back().stop, stream);
 }
 
-// Items per pass of the encoder chain: bounds the activation scratch
-// (2 x chunk x widest hidden layer) while keeping every GEMM launch >> 256 tiles.
-constexpr int64_t ENC_CHUNK = 131072;
+// Items per pass of the encoder chain: bounds the activation scratch (2 x chunk x widest hidden layer per pipeline: 8.6 GB at
+// 524 288 x 2048 floats, of a 288 GB part) while keeping every GEMM launch >> 256 tiles.  Measured on C3 (round 3, one box, M
+// items/s): 65 536: 16.26, 131 072 (rounds 1-2): 16.40, 262 144: 16.46, 524 288: 16.51 -- the dominant kernel's own rate does not
+// move (0.930 of the roof throughout); fewer, longer launches mean fewer exposed first / last tiles of the narrow layers and
+// fewer dispatch gaps.  Results do not depend on it (every output is one chain over k).
+#ifndef LCREC_ENC_CHUNK
+#define LCREC_ENC_CHUNK 524288
+#endif
+constexpr int64_t ENC_CHUNK = LCREC_ENC_CHUNK;
 constexpr int ENC_PIPES_MAX = 2;      // measured: a third and fourth pipeline add nothing (and cost 2 GB of scratch each)
 
 struct EncLayout {
@@ -218,6 +224,8 @@ LCREC_API size_t lcrec_encode_assign_workspace(int64_t n, const int *dims, int n
     EncLayout o = enc_layout(n, dims, n_layers, K, L);
     return 2 * ENC_PIPES_MAX * o.act_bytes + o.latent_bytes + o.rq_bytes;      // an activation ping-pong pair per chunk pipeline
 }
+
+LCREC_API int64_t lcrec_encode_assign_chunk_rows(void) { return ENC_CHUNK; }
 
 LCREC_API int lcrec_encode_assign(const float *x, int64_t n, const int *dims, int n_layers,
                                   const float *const *W, const float *const *b,

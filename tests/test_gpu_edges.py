@@ -154,7 +154,7 @@ def test_context_pipelines_and_lifetime(hip):
     bs = [0.01 * torch.randn(dims[l + 1], generator=g, device=dev) for l in range(3)]
     cbs = [torch.randn((64, 32), generator=g, device=dev) * 0.5 ** l for l in range(3)]
     flat, ks = ops.flatten_codebooks(cbs)
-    x = torch.randn((400_000, 256), generator=g, device=dev)               # 4 chunks of 131 072: both pipelines get work
+    x = torch.randn((3 * hip._lib.load().lcrec_encode_assign_chunk_rows() + 1000, 256), generator=g, device=dev)   # 4 chunks (the last ragged): both pipelines get work
     try:
         ops.set_pipelines(1)
         one = ops.encode_assign(x, Ws, bs, flat, ks, want_latent=True)
