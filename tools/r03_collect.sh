@@ -24,5 +24,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$o/prof_bench_c3 -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/$o/prof_bench_c3.log 2>&1; echo "rocprof bench rc=$?"
 cd $GRAFT_REPO_ROOT
 python tools/rocpd_summary.py stats $o/prof_bench_c3/b_results.db > $o/bench_c3_kernel_stats.csv; head -5 $o/bench_c3_kernel_stats.csv | cut -c1-140
-tail -1 $o/prof_bench_c3.log > $o/bench_c3_profiled.json
+grep -a "^{\"metric" $o/prof_bench_c3.log | tail -1 > $o/bench_c3_profiled.json
 rm -f $o/prof_bench_c3/b_results.db $o/prof_train_b1024_bn1/tr_results.db $o/prof_train_b1024_bn1_fused/tr_results.db
