@@ -224,3 +224,69 @@ def test_two_gpus_over_rccl_reproduce_the_single_process_epoch(hip, tmp_path, dp
     assert int(two["collectives"]) > 0 and (int(two["replays"]) > 0) == (dp_graph == "on")
     np.testing.assert_allclose(two["losses"], one["losses"], rtol=2e-4)
     assert float(two["rate"]) == pytest.approx(float(one["rate"]), abs=2e-2)
+
+
+def _one_step(rank, world, port, tmp, bn):
+    """ONE engine step at learning rate 0 (first step of a linear warm-up) on a fixed global batch; the gradient buffer is saved."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if world > 1:
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    else:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+    import argparse
+    import lcrec_amd
+    from lcrec_amd import dist as ldist
+    from lcrec_amd.engine import TrainEngine
+    ctx = ldist.init_from_env(argparse.Namespace(device="cuda:0"), backend="gloo")
+    torch.manual_seed(5)
+    model = lcrec_amd.RQVAE(in_dim=96, num_emb_list=[64] * 3, e_dim=32, layers=[256, 128, 64], bn=bn, kmeans_init=False,
+                            sk_epsilons=[0.0, 0.0, 0.003], sk_iters=50).to("cuda:0").train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((509, 96), generator=g).to("cuda:0")                 # 509 rows: 255 + 254 on two ranks
+    with torch.no_grad():
+        z = model.eval().encoder(x)
+        for l, q in enumerate(model.rq.vq_layers):
+            q.embedding.weight.copy_(z[l * 64:(l + 1) * 64] * 0.7 ** l)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    eng = TrainEngine(model, opt, "linear", 2, 10, dist=ctx if ctx.enabled else None, use_graph=False)
+    lo, hi = ldist.batch_slice(509, ctx.rank, ctx.world_size)
+    if ctx.enabled:
+        ctx.set_batch(hi - lo, 509)
+    eng.step(x[lo:hi].contiguous())
+    torch.cuda.synchronize()
+    if ctx.rank == 0:
+        out = {k: (p.grad / eng.clip[1]).cpu().numpy() for k, p in model.named_parameters()}
+        np.savez(os.path.join(tmp, f"step{world}.npz"), loss=eng.last.cpu().numpy(), norm=eng.clip[0].item(), **out)
+    ldist.shutdown(ctx)
+
+
+@pytest.mark.parametrize("bn", [False, True])
+def test_two_ranks_compute_the_single_process_gradient(hip, tmp_path, bn):
+    """The sharper form of the epoch comparison above: ONE step (learning rate 0, so nothing is amplified by Adam's
+    normalisation), the all-reduced gradient of two ranks holding 255 + 254 rows of a global batch against the
+    single-process gradient of the 509 rows, tensor by tensor -- losses and gradient norm to 1e-5, every gradient tensor
+    to 1e-4 of its norm (BatchNorm: global-batch statistics merged in rank order, (sum g, sum g xhat) all-reduced; the
+    Sinkhorn level solved on the gathered batch; the quantiser's counts are those of the global batch)."""
+    tmp = str(tmp_path)
+    mp.spawn(_one_step, args=(1, 0, tmp, bn), nprocs=1, join=True)
+    mp.spawn(_one_step, args=(2, _free_port(), tmp, bn), nprocs=2, join=True)
+    one, two = np.load(os.path.join(tmp, "step1.npz")), np.load(os.path.join(tmp, "step2.npz"))
+    np.testing.assert_allclose(two["loss"], one["loss"], rtol=1e-5)
+    np.testing.assert_allclose(float(two["norm"]), float(one["norm"]), rtol=1e-5)
+    worst = {}
+    for k in one.files:
+        if k in ("loss", "norm"):
+            continue
+        a, b = one[k].astype(np.float64), two[k].astype(np.float64)
+        na = np.linalg.norm(a)
+        if bn and k.endswith(".bias") and one[k.replace(".bias", ".weight")].ndim == 2:
+            part, _, idx, _ = k.split(".")
+            nxt = f"{part}.mlp_layers.{int(idx) + 1}.weight"
+            if nxt in one.files and one[nxt].ndim == 1:
+                continue                               # a Linear bias in front of a BatchNorm: true gradient 0, rounding noise
+        worst[k] = np.linalg.norm(a - b) / max(na, 1e-30)
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    assert not bad, bad
