@@ -18,6 +18,8 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <stdint.h>
+#include <initializer_list>
 
 namespace lcrec {
 
@@ -37,7 +39,16 @@ struct Strip {
     static constexpr int RGS = CR_THREADS / COLS;
     int c, rg, col;
     bool live;
-    __device__ Strip(int F) : c(threadIdx.x % COLS), rg(threadIdx.x / COLS), col(blockIdx.x * COLS + threadIdx.x % COLS), live(col < F) {}
+    // Strips are narrower than a 128-byte line (32 floats), so neighbours share lines -- and consecutive workgroups go to different
+    // XCDs (round-robin over 8), each with an L2 of its own that would fetch the shared line again.  When the grid is a multiple
+    // of 8, workgroup b takes strip (b % 8) * (grid / 8) + b / 8: the strips of one XCD are neighbours (measured on the float4
+    // form below: backward of 1024 x 2048 in 16-column strips 13.3 -> 8.0 us).
+    static __device__ __forceinline__ int strip_of_block()
+    {
+        const int b = blockIdx.x, g = gridDim.x;
+        return (COLS < 32 && (g & 7) == 0) ? (b & 7) * (g >> 3) + (b >> 3) : b;
+    }
+    __device__ Strip(int F) : c(threadIdx.x % COLS), rg(threadIdx.x / COLS), col(strip_of_block() * COLS + threadIdx.x % COLS), live(col < F) {}
 
     // f(row) -> value; returns the sum over this lane's rows in ascending row order
     template <typename Fn>
@@ -249,6 +260,247 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const floa
         if (dgamma) dgamma[col] = dg;
         if (dbeta) dbeta[col] = db;
         if (dbias) dbias[col] = dbs;
+    }
+}
+
+// ---- the two kernels again for the shapes a training step has: F a multiple of 4, rows 16-byte aligned, and few enough rows
+// that a lane's share of the strip stays in registers (n <= RMAX * RGS).  Lanes read float4s: a strip of COLS columns is COLS / 4
+// lanes wide and RGS = 1024 / (COLS / 4) row groups deep, so a 1024 x 16 strip is FOUR 16-byte loads per lane and array, all in
+// flight at once, where the dword form above issues 16 per lane -- on one CU the dword form is bound by the texture-address
+// rate (13 us for a 1024 x 16 backward strip however few strips the launch has; r03 kernel trace by grid size).
+// Row order of the sums: lane rows ascending, then the xor tree over the wave's row groups, then the 16 waves in order.
+template <int COLS>
+struct Strip4 {
+    static constexpr int L4 = COLS / 4, RGS = CR_THREADS / L4;
+    int c4, rg, col;
+    bool live;
+    // the strip of a workgroup: neighbours on one XCD, as in Strip::strip_of_block
+    static __device__ __forceinline__ int strip_of_block()
+    {
+        const int b = blockIdx.x, g = gridDim.x;
+        return (COLS < 32 && (g & 7) == 0) ? (b & 7) * (g >> 3) + (b >> 3) : b;
+    }
+    __device__ Strip4(int F) : c4(threadIdx.x % L4), rg(threadIdx.x / L4), col(strip_of_block() * COLS + 4 * (threadIdx.x % L4)), live(col < F) {}
+
+    // v + (v rotated right by N lanes within its row of 16 lanes): one v_add_f32 with a DPP operand, no LDS crossbar
+    template <int N>
+    static __device__ __forceinline__ float add_ror(float v)
+    {
+        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+    }
+
+    // sums over all row groups of NV four-column values per lane; valid in every lane afterwards.
+    //  1. inside a row of 16 lanes (16 / L4 row groups): DPP rotations, so lane c4 of the row ends with the row's sum of its
+    //     columns (each lane adds in its own rotated order; only lanes c4 < L4 of each row are used, a fixed order);
+    //  2. the 64 row partials of the workgroup (16 waves x 4 rows) through LDS, added by ONE lane per (value, column) as four
+    //     chains of 16 in row order -- every lane reading all partials of its four columns would be 8x the LDS traffic;
+    //  3. the totals back through LDS.
+    template <int NV>
+    __device__ __forceinline__ void sum(float (&v)[NV][4], float *sm) const
+    {
+        constexpr int PR = CR_WAVES * 4;                                          // partial rows
+        float(*part)[NV * COLS] = reinterpret_cast<float(*)[NV * COLS]>(sm);     // [PR][NV * COLS]
+        float *tot = sm + PR * NV * COLS;                                        // [NV * COLS]
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (L4 <= 1) v[q][e] = add_ror<1>(v[q][e]);
+                if (L4 <= 2) v[q][e] = add_ror<2>(v[q][e]);
+                if (L4 <= 4) v[q][e] = add_ror<4>(v[q][e]);
+                if (L4 <= 8) v[q][e] = add_ror<8>(v[q][e]);
+            }
+        __syncthreads();                       // previous use of sm is over
+        if ((threadIdx.x & 15) < L4)
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+                *reinterpret_cast<float4 *>(&part[threadIdx.x >> 4][q * COLS + 4 * c4]) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+        __syncthreads();
+        if (threadIdx.x < NV * COLS) {
+            float a[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) a[h] = part[h * (PR / 4)][threadIdx.x];
+#pragma unroll 3                              // 12 reads in flight: fully unrolled, the 64 of them crowd out the cached rows
+            for (int w = 1; w < PR / 4; ++w)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) a[h] += part[h * (PR / 4) + w][threadIdx.x];
+            tot[threadIdx.x] = (a[0] + a[1]) + (a[2] + a[3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float4 a = *reinterpret_cast<const float4 *>(&tot[q * COLS + 4 * c4]);
+            v[q][0] = a.x; v[q][1] = a.y; v[q][2] = a.z; v[q][3] = a.w;
+        }
+    }
+    static constexpr int SM_FLOATS = (CR_WAVES * 4 + 1) * 2 * COLS;      // for NV <= 2
+};
+
+__device__ __forceinline__ void ld4(float (&d)[4], const float *p)
+{
+    const float4 q = *reinterpret_cast<const float4 *>(p);
+    d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+}
+__device__ __forceinline__ void st4(float *p, const float (&d)[4]) { *reinterpret_cast<float4 *>(p) = make_float4(d[0], d[1], d[2], d[3]); }
+
+template <int COLS, int RMAX>
+__global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_v4_kernel(const float *__restrict__ t, int64_t n, int F,
+                                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                         float eps, float momentum, float *running_mean,
+                                                                         float *running_var, float *__restrict__ y, float *mean_out,
+                                                                         float *rstd_out, int relu)
+{
+    using S = Strip4<COLS>;
+    __shared__ __attribute__((aligned(16))) float sm[S::SM_FLOATS];
+    const S st(F);
+    const int col = st.live ? st.col : 0;          // dead lanes read columns 0..3 and write nothing
+    const float inv_n = 1.0f / (float)n;
+    const float *tc = t + col;
+    float pivot[4];                                // the columns' first row, as in the dword form
+    ld4(pivot, tc);
+    float tv[RMAX][4];
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int r = st.rg + u * S::RGS;         // 32-bit offsets from the uniform base (n * F < 2^29)
+        ld4(tv[u], t + ((unsigned)(r < (int)n ? r : 0) * (unsigned)F + (unsigned)col));      // no branch between the loads; rows past n read the pivot row: exact zeros below
+    }
+    float s[2][4] = {};
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = tv[u][e] - pivot[e];
+            s[0][e] += d;
+            s[1][e] += d * d;
+        }
+    float g[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {};          // in flight with the rows
+    if (gamma) ld4(g, gamma + col);
+    if (beta) ld4(b, beta + col);
+    st.template sum<2>(s, sm);
+    if (!st.live) return;
+    float mean[4], rstd[4], m2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float dmean = s[0][e] * inv_n;
+        mean[e] = pivot[e] + dmean;
+        const float m = s[1][e] - s[0][e] * dmean;
+        m2[e] = m > 0.f ? m : 0.f;
+        rstd[e] = 1.0f / __builtin_sqrtf(m2[e] * inv_n + eps);
+    }
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        const int r = st.rg + u * S::RGS;
+        if (r < (int)n) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (tv[u][e] - mean[e]) * rstd[e] * g[e] + b[e];
+                if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            st4(y + ((unsigned)r * (unsigned)F + (unsigned)col), v);
+        }
+    }
+    if (st.rg == 0) {
+        st4(mean_out + col, mean);
+        st4(rstd_out + col, rstd);
+        if (running_mean) {
+            float rm[4];
+            ld4(rm, running_mean + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rm[e] = (1.0f - momentum) * rm[e] + momentum * mean[e];
+            st4(running_mean + col, rm);
+        }
+        if (running_var) {
+            float rv[4];
+            ld4(rv, running_var + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float unbiased = n > 1 ? m2[e] / (float)(n - 1) : m2[e] * inv_n;
+                rv[e] = (1.0f - momentum) * rv[e] + momentum * unbiased;
+            }
+            st4(running_var + col, rv);
+        }
+    }
+}
+
+template <int COLS, int RMAX>
+__global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_v4_kernel(const float *gy, const float *__restrict__ t,
+                                                                          const float *__restrict__ y, int64_t n, int F,
+                                                                          const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                                          const float *__restrict__ rstd, int relu, float *dt,
+                                                                          float *dgamma, float *dbeta, float *dbias,
+                                                                          const float *__restrict__ fold_scale,
+                                                                          const float *__restrict__ fold_shift)
+{
+    using S = Strip4<COLS>;
+    __shared__ __attribute__((aligned(16))) float sm[S::SM_FLOATS];
+    const S st(F);
+    const int col = st.live ? st.col : 0;
+    float mu[4], rs[4], gm[4] = {1.f, 1.f, 1.f, 1.f}, fs[4] = {}, fh[4] = {};
+    ld4(mu, mean + col);
+    ld4(rs, rstd + col);
+    if (gamma) ld4(gm, gamma + col);
+    const bool from_y = relu && y, from_fold = relu && !y;     // the ReLU mask: stored activation, or the consumer's fused expression
+    if (from_fold) { ld4(fs, fold_scale + col); ld4(fh, fold_shift + col); }
+    float gv[RMAX][4], xv[RMAX][4];               // the lane's masked gradients and xhat, read once
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+        // Four rows per lane: every load issued unconditionally (rows past n read row 0 and are zeroed) -- no branch, nothing
+        // waits between the 12 loads.  Eight rows per lane: a branch per row keeps the compiler from hoisting all 24 loads, which
+        // do not fit the 128 registers a 1024-thread workgroup leaves each lane (measured with the spills: 8.8 -> 13.8 us at
+        // 1024 x 2048 in 32-column strips).
+        const int r = st.rg + u * S::RGS;
+        const bool in = r < (int)n;
+        const unsigned off = (unsigned)(in ? r : 0) * (unsigned)F + (unsigned)col;      // one 32-bit offset for the three arrays (n * F < 2^29)
+        if (RMAX <= 4 || in) {
+            float tt[4], yy[4] = {1.f, 1.f, 1.f, 1.f};
+            ld4(gv[u], gy + off);
+            ld4(tt, t + off);
+            if (from_y) ld4(yy, y + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool on = from_fold ? __builtin_fmaf(tt[e], fs[e], fh[e]) > 0.f : yy[e] > 0.f;
+                gv[u][e] = (in && on) ? gv[u][e] : 0.f;
+                xv[u][e] = in ? (tt[e] - mu[e]) * rs[e] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gv[u][e] = 0.f; xv[u][e] = 0.f; }
+        }
+    }
+    float s[2][4] = {};
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s[0][e] += gv[u][e];
+            s[1][e] += gv[u][e] * xv[u][e];
+        }
+    st.template sum<2>(s, sm);
+    const float inv_n = 1.0f / (float)n;
+    float k[4], mdb[4], mdg[4], sdt[1][4] = {};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { k[e] = gm[e] * rs[e]; mdb[e] = s[0][e] * inv_n; mdg[e] = s[1][e] * inv_n; }
+    if (st.live) {
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) {
+            const int r = st.rg + u * S::RGS;
+            if (r < (int)n) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = k[e] * (gv[u][e] - mdb[e] - xv[u][e] * mdg[e]);
+                    sdt[0][e] += v[e];
+                }
+                st4(dt + ((unsigned)r * (unsigned)F + (unsigned)col), v);
+            }
+        }
+    }
+    st.template sum<1>(sdt, sm);
+    if (st.live && st.rg == 0) {
+        if (dgamma) st4(dgamma + col, s[1]);
+        if (dbeta) st4(dbeta + col, s[0]);
+        if (dbias) st4(dbias + col, sdt[0]);
     }
 }
 
@@ -687,6 +939,34 @@ static int strip_cols(int F)
         else { if (cached_) hipLaunchKernelGGL((KERN<8, true>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((KERN<8, false>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); } \
     } while (0)
 
+// The float4 strip kernels: strip width for (n, F), or 0 when the shape is not theirs (F not a multiple of 4, a pointer off
+// 16-byte alignment, or more rows than rmax per lane at the narrowest strip) -- then the dword kernels above run.
+static int strip4_cols(int64_t n, int F, int rmax, std::initializer_list<const void *> ptrs)
+{
+    static const int mode = [] { const char *e = getenv("LCREC_BN_V4"); return e ? atoi(e) : 16; }();   // 0 off; 8 / 32 force a strip width, 161 = 32 from 2048 columns (tuning)
+    if (!mode || (F & 3) || n * F >= ((int64_t)1 << 29)) return 0;       // 32-bit byte offsets inside the kernels
+    for (const void *p : ptrs)
+        if ((uintptr_t)p & 15) return 0;
+    // measured per call at 1024 rows (tools/bn_probe.py): backward 2048 columns 13.5 us at 16-column strips, 8.8 us at 32 (whole
+    // 128-byte lines per row); 1024 columns and fewer the same or better at 16 (more workgroups)
+    int cols = mode == 8 || mode == 32 ? mode : (mode == 161 && F >= 2048 ? 32 : 16);
+    while (cols > 8 && n > (int64_t)rmax * (CR_THREADS / (cols / 4))) cols /= 2;
+    return n <= (int64_t)rmax * (CR_THREADS / (cols / 4)) ? cols : 0;
+}
+// rows per lane: 4 or 8 by n
+#define LCREC_STRIP4_R8(KERN, COLS_, n, grid_, stream, ...)                                                            \
+    do {                                                                                                              \
+        if ((n) <= 4 * (CR_THREADS / (COLS_ / 4))) hipLaunchKernelGGL((KERN<COLS_, 4>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERN<COLS_, 8>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);                    \
+    } while (0)
+#define LCREC_STRIP4_LAUNCH(RSEL, KERN, cols, n, F, stream, ...)                                                       \
+    do {                                                                                                              \
+        const dim3 grid_((unsigned)(((F) + (cols) - 1) / (cols)));                                                    \
+        if ((cols) == 32) RSEL(KERN, 32, n, grid_, stream, __VA_ARGS__);                                              \
+        else if ((cols) == 16) RSEL(KERN, 16, n, grid_, stream, __VA_ARGS__);                                         \
+        else RSEL(KERN, 8, n, grid_, stream, __VA_ARGS__);                                                            \
+    } while (0)
+
 int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const float *beta, float eps, float momentum,
                     float *running_mean, float *running_var, float *y, float *mean_out, float *rstd_out, int relu,
                     hipStream_t stream)
@@ -696,6 +976,12 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
     if (n < 2) return fail(LCREC_EINVAL, "bn_relu_forward: training-mode BatchNorm needs more than 1 row (n=%lld)", (long long)n);
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_forward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_FWD, stream);
+    const int v4 = strip4_cols(n, F, 8, {t, y, gamma, beta, running_mean, running_var, mean_out, rstd_out});
+    if (v4) {
+        LCREC_STRIP4_LAUNCH(LCREC_STRIP4_R8, bn_relu_forward_v4_kernel, v4, n, F, stream, t, n, F, gamma, beta, eps, momentum, running_mean, running_var, y,
+                            mean_out, rstd_out, relu);
+        return check_launch("bn_relu_forward_v4_kernel");
+    }
     LCREC_STRIP_LAUNCH_N(bn_relu_forward_kernel, F, n, stream, t, n, F, gamma, beta, eps, momentum, running_mean, running_var, y,
                          mean_out, rstd_out, relu);
     return check_launch("bn_relu_forward_kernel");
@@ -710,6 +996,12 @@ int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n,
         return fail(LCREC_EINVAL, "bn_relu_backward: NULL pointer (with relu: y, or fold_scale and fold_shift)");
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_backward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_BWD, stream);
+    const int v4 = strip4_cols(n, F, 8, {gy, t, y, gamma, mean, rstd, dt, dgamma, dbeta, dbias, fold_scale, fold_shift});
+    if (v4) {
+        LCREC_STRIP4_LAUNCH(LCREC_STRIP4_R8, bn_relu_backward_v4_kernel, v4, n, F, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta,
+                            dbias, fold_scale, fold_shift);
+        return check_launch("bn_relu_backward_v4_kernel");
+    }
     LCREC_STRIP_LAUNCH_N(bn_relu_backward_kernel, F, n, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias,
                          fold_scale, fold_shift);
     return check_launch("bn_relu_backward_kernel");

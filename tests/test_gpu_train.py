@@ -22,7 +22,8 @@ def _rs(seed):
     return np.random.RandomState(seed)
 
 
-@pytest.mark.parametrize("n,feat,relu", [(1024, 2048, True), (475, 96, True), (2, 32, True), (2048, 64, False), (333, 100, True)])
+@pytest.mark.parametrize("n,feat,relu", [(1024, 2048, True), (475, 96, True), (2, 32, True), (2048, 64, False), (333, 100, True),
+                                          (4096, 64, True), (5000, 36, True), (300, 66, True), (1025, 24, False)])
 def test_bn_relu_forward_backward_match_torch(hip, n, feat, relu):
     rs = _rs(n + feat)
     t = gi.f32(rs.standard_normal((n, feat)) * 2.0 + rs.standard_normal(feat) * 3.0)       # means far from 0
@@ -500,22 +501,19 @@ def test_run_sh_step_gradients_against_the_fp64_reference(hip, path):
 
     def judge(grads, scalars, idx, what):
         flipped = int((idx != g["idx"].astype(np.int64)).any(1).sum())
-        if path == "engine-fused-bn":
-            # the folded BatchNorm evaluates t * (gamma * rstd) + (beta - mean * gamma * rstd) in one fma: latents differ from the
-            # three-step form in the last bit, which may flip a near-tied assignment or two of the 1024 -- a different (equally
-            # valid) problem for those rows, so the gradient bounds below get room for it
-            assert flipped <= 3, (what, flipped)
-        else:
-            assert flipped == 0, what
-        loose = 4.0 if flipped else 1.0
-        np.testing.assert_allclose(scalars[:3], want[:3], rtol=1e-5 * (10 if flipped else 1), err_msg=what)   # loss, recon, rq_loss
-        np.testing.assert_allclose(scalars[3], want[3], rtol=1e-4 * loose, err_msg=what)         # gradient norm before clipping
-        rows, bad = f11_check.report(g, grads)
+        # An evaluation whose latents differ in the last bit (BatchNorm statistics summed in another order; the folded form's
+        # single fma) may send a near-tied row or two of the 1024 to another code on the Sinkhorn level: a different, equally
+        # valid problem for those rows, not different arithmetic.  Then the yardstick is the fp64 evaluation of THAT problem
+        # (f11_check.f64_gradients_for: the oracle's torch restatement in fp64 with the codes forced; with the fixture's codes
+        # it reproduces the reference's fp64 run to 1e-9, tests/test_oracle_golden.py) -- same bounds, nothing loosened.
+        assert flipped <= 3, (what, flipped)
+        target, f64 = want, None
+        if flipped:
+            target, f64 = f11_check.f64_gradients_for(g, idx)
+        np.testing.assert_allclose(scalars[:3], target[:3], rtol=1e-5, err_msg=what)      # loss, recon, rq_loss
+        np.testing.assert_allclose(scalars[3], target[3], rtol=1e-4, err_msg=what)        # gradient norm before clipping
+        rows, bad = f11_check.report(g, grads, f64)
         print(f"\n[{what}] rows assigned differently: {flipped}\n" + f11_check.table(rows))
-        # (a row with another code is another problem, not other arithmetic: two of 1024 move the encoder's gradient by ~2 % of its
-        # norm -- the per-tensor bounds then say nothing; the folded kernels themselves are pinned bit for bit by
-        # test_linear_bn_forward_is_the_oracle_chain_with_batch_statistics / test_folded_batchnorm_operands_in_the_backward_products)
-        bad = [b for b in bad if not flipped and not b[2] <= b[4]]
         assert not bad, what + "\n" + f11_check.table(bad)
 
     if path == "autograd":

@@ -41,6 +41,21 @@ def stats(db):
         print(f'"{name}",{calls},{tot},{avg:.1f},{100.0 * tot / total:.4f},{lo},{hi}')
 
 
+def bygrid(db):
+    """Per (kernel, grid) table: the same kernel at different problem sizes (the layers of the MLP) apart."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
+    wx = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else None)
+    if not gx or not wx:
+        sys.exit(f"kernels view has no grid columns: {cols}")
+    rows = c.execute(f"select name, {gx}, {wx}, count(*), avg(end-start), min(end-start), max(end-start) from kernels "
+                     f"group by name, {gx}, {wx} order by name, {gx}").fetchall()
+    print('"Name","GridX","WorkgroupX","Calls","AverageNs","MinNs","MaxNs"')
+    for name, g, w, calls, avg, lo, hi in rows:
+        print(f'"{name[:100]}",{g},{w},{calls},{avg:.1f},{lo},{hi}')
+
+
 def counter(db, which):
     acc = collections.defaultdict(list)
     c = sqlite3.connect(db)
@@ -147,6 +162,8 @@ def main():
     sub = ap.add_subparsers(dest="cmd", required=True)
     s = sub.add_parser("stats")
     s.add_argument("db")
+    g = sub.add_parser("bygrid")
+    g.add_argument("db")
     p = sub.add_parser("pmc")
     p.add_argument("--fetch", required=True)
     p.add_argument("--write", required=True)
@@ -159,6 +176,8 @@ def main():
         mfma(a.dbs)
     elif a.cmd == "stats":
         stats(a.db)
+    elif a.cmd == "bygrid":
+        bygrid(a.db)
     else:
         pmc(a)
 
