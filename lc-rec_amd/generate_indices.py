@@ -344,7 +344,7 @@ def generate(ckpt_path, output_file, device="cuda:0", data_path=None, verbose=Tr
     verbose = verbose and lead
     ckpt = load_checkpoint(ckpt_path, trust=trust_checkpoint)
     args = ckpt["args"]
-    data = EmbDataset(data_path or args.data_path, mmap=ctx.enabled)
+    data = EmbDataset(data_path or args.data_path, mmap=ctx.enabled or str(device).startswith("cuda"))
     model = build_model_from_args(args, data.dim)
     model.load_state_dict(ckpt["state_dict"])
     model = model.to(torch.device(device)).eval()

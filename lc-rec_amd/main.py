@@ -119,7 +119,8 @@ def main(argv=None):
 
     from . import dist as ldist
     ctx = ldist.init_from_env(args)          # single process unless launched under torchrun
-    data = EmbDataset(args.data_path)
+    # to a GPU the file goes from the page cache through the pinned ring of EmbDataset.to_device: no host copy of the matrix
+    data = EmbDataset(args.data_path, mmap=str(args.device).startswith("cuda"))
     model = build_model(args, data.dim)
     if getattr(args, "reset_seed", None) is not None and str(args.device).startswith("cuda"):
         for l, q in enumerate(model.rq.vq_layers):      # one stream of draws per level, the same on every rank

@@ -196,3 +196,23 @@ def test_bench_line_and_its_collective_path_over_a_one_rank_rccl_group(hip):
     assert "error" not in dp and dp["train_ranks_seen"] == 1 and dp["dp_collectives_per_step"] >= 20
     assert dp["train_param_checksums_agree_eager"] and dp["train_param_checksums_agree_graph"]
     assert 0.3 < dp["dp_train_step_ms_eager"] < 50 and dp["dp_train_graph_replays_graph"] > 0 and dp["dp_train_graph_replays_eager"] == 0
+
+
+@pytest.mark.parametrize("dtype,mmap", [(np.float32, True), (np.float16, True), (np.float64, False)])
+def test_embedding_file_reaches_hbm_through_the_pinned_ring(tmp_path, dtype, mmap):
+    """EmbDataset.to_device on a GPU (host threads fill a ring of pinned chunks, H2D copies queued in order): every row of the
+    file, cast to fp32, for chunk sizes that do and do not divide the row count, more chunks than ring slots, a rank's row range."""
+    from lcrec_amd.datasets import EmbDataset
+    rs = np.random.RandomState(5)
+    a = rs.standard_normal((1237, 96)).astype(dtype)
+    path = str(tmp_path / "T.emb-x-td.npy")
+    np.save(path, a)
+    want = torch.from_numpy(a.astype(np.float32))
+    for chunk, workers, stages in ((None, None, None), (100, 3, 4), (1, 2, 2), (1237, 8, 3), (5000, 1, 2)):
+        ds = EmbDataset(path, mmap=mmap)
+        got = ds.to_device("cuda:0", chunk_rows=chunk, workers=workers, stages=stages)
+        assert got.dtype == torch.float32 and torch.equal(got.cpu(), want), (chunk, workers, stages)
+        assert ds.to_device("cuda:0") is got                                     # kept: the loader and the index pass share it
+        part = EmbDataset(path, mmap=mmap).to_device("cuda:0", chunk_rows=chunk, rows=(300, 1001), workers=workers, stages=stages)
+        assert torch.equal(part.cpu(), want[300:1001])
+    assert EmbDataset(path, mmap=mmap).to_device("cuda:0", rows=(7, 7)).shape == (0, 96)
