@@ -343,7 +343,8 @@ __device__ __forceinline__ void ld4(float (&d)[4], const float *p)
 }
 __device__ __forceinline__ void st4(float *p, const float (&d)[4]) { *reinterpret_cast<float4 *>(p) = make_float4(d[0], d[1], d[2], d[3]); }
 
-template <int COLS, int RMAX>
+// STATS: only the local statistics of a rank's rows (lcrec_bn_stats: mean -> mean_out, M2 -> rstd_out), nothing applied
+template <int COLS, int RMAX, bool STATS = false>
 __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_v4_kernel(const float *__restrict__ t, int64_t n, int F,
                                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                          float eps, float momentum, float *running_mean,
@@ -381,11 +382,15 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_v4_kernel(const fl
     float mean[4], rstd[4], m2[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float dmean = s[0][e] * inv_n;
+        const float dmean = STATS ? s[0][e] / (float)n : s[0][e] * inv_n;        // (bn_stats_kernel divides; keep its expression)
         mean[e] = pivot[e] + dmean;
         const float m = s[1][e] - s[0][e] * dmean;
         m2[e] = m > 0.f ? m : 0.f;
         rstd[e] = 1.0f / __builtin_sqrtf(m2[e] * inv_n + eps);
+    }
+    if (STATS) {
+        if (st.rg == 0) { st4(mean_out + col, mean); st4(rstd_out + col, m2); }
+        return;
     }
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
@@ -423,25 +428,36 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_forward_v4_kernel(const fl
     }
 }
 
-template <int COLS, int RMAX>
-__global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_v4_kernel(const float *gy, const float *__restrict__ t,
-                                                                          const float *__restrict__ y, int64_t n, int F,
-                                                                          const float *__restrict__ gamma, const float *__restrict__ mean,
-                                                                          const float *__restrict__ rstd, int relu, float *dt,
-                                                                          float *dgamma, float *dbeta, float *dbias,
-                                                                          const float *__restrict__ fold_scale,
-                                                                          const float *__restrict__ fold_shift)
+struct Bn4Bwd {
+    const float *gy, *t, *y;
+    int64_t n;
+    int F;
+    const float *gamma, *mean, *rstd;
+    int relu;
+    float *dt, *dgamma, *dbeta, *dbias;
+    const float *fold_scale, *fold_shift;
+    float *sum_g, *sum_gx;      // MODE 1: out, this rank's column sums of g and g * xhat; MODE 2: in, the sums over all ranks
+    float n_total;              // MODE 2: rows of the global batch
+};
+// MODE 0: the whole backward of one process.  The data-parallel split (SyncBatchNorm semantics, lcrec_amd/layers.py all-reduces
+// between the halves): MODE 1 = lcrec_bn_backward_reduce (the two column sums of this rank's rows, nothing written to dt),
+// MODE 2 = lcrec_bn_backward_apply (dt and dbias from the global sums).
+template <int COLS, int RMAX, int MODE = 0>
+__global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_v4_kernel(Bn4Bwd p)
 {
     using S = Strip4<COLS>;
     __shared__ __attribute__((aligned(16))) float sm[S::SM_FLOATS];
+    const float *gy = p.gy, *__restrict__ t = p.t, *__restrict__ y = p.y;
+    const int64_t n = p.n;
+    const int F = p.F, relu = p.relu;
     const S st(F);
     const int col = st.live ? st.col : 0;
     float mu[4], rs[4], gm[4] = {1.f, 1.f, 1.f, 1.f}, fs[4] = {}, fh[4] = {};
-    ld4(mu, mean + col);
-    ld4(rs, rstd + col);
-    if (gamma) ld4(gm, gamma + col);
+    ld4(mu, p.mean + col);
+    ld4(rs, p.rstd + col);
+    if (MODE != 1 && p.gamma) ld4(gm, p.gamma + col);
     const bool from_y = relu && y, from_fold = relu && !y;     // the ReLU mask: stored activation, or the consumer's fused expression
-    if (from_fold) { ld4(fs, fold_scale + col); ld4(fh, fold_shift + col); }
+    if (from_fold) { ld4(fs, p.fold_scale + col); ld4(fh, p.fold_shift + col); }
     float gv[RMAX][4], xv[RMAX][4];               // the lane's masked gradients and xhat, read once
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
@@ -476,8 +492,23 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_v4_kernel(const f
             s[0][e] += gv[u][e];
             s[1][e] += gv[u][e] * xv[u][e];
         }
-    st.template sum<2>(s, sm);
-    const float inv_n = 1.0f / (float)n;
+    if (MODE == 2) {
+        ld4(s[0], p.sum_g + col);
+        ld4(s[1], p.sum_gx + col);
+    } else {
+        st.template sum<2>(s, sm);
+    }
+    if (MODE == 1) {
+        if (st.live && st.rg == 0) {
+            st4(p.sum_g + col, s[0]);
+            st4(p.sum_gx + col, s[1]);
+            if (p.dbeta) st4(p.dbeta + col, s[0]);           // this rank's share of the parameter gradients
+            if (p.dgamma) st4(p.dgamma + col, s[1]);
+        }
+        return;
+    }
+    float *dt = p.dt, *dgamma = MODE == 0 ? p.dgamma : nullptr, *dbeta = MODE == 0 ? p.dbeta : nullptr, *dbias = p.dbias;
+    const float inv_n = 1.0f / (MODE == 2 ? p.n_total : (float)n);
     float k[4], mdb[4], mdg[4], sdt[1][4] = {};
 #pragma unroll
     for (int e = 0; e < 4; ++e) { k[e] = gm[e] * rs[e]; mdb[e] = s[0][e] * inv_n; mdg[e] = s[1][e] * inv_n; }
@@ -954,17 +985,17 @@ static int strip4_cols(int64_t n, int F, int rmax, std::initializer_list<const v
     return n <= (int64_t)rmax * (CR_THREADS / (cols / 4)) ? cols : 0;
 }
 // rows per lane: 4 or 8 by n
-#define LCREC_STRIP4_R8(KERN, COLS_, n, grid_, stream, ...)                                                            \
+#define LCREC_STRIP4_R8(KERN, COLS_, MODE_, n, grid_, stream, ...)                                                     \
     do {                                                                                                              \
-        if ((n) <= 4 * (CR_THREADS / (COLS_ / 4))) hipLaunchKernelGGL((KERN<COLS_, 4>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERN<COLS_, 8>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);                    \
+        if ((n) <= 4 * (CR_THREADS / (COLS_ / 4))) hipLaunchKernelGGL((KERN<COLS_, 4, MODE_>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERN<COLS_, 8, MODE_>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);             \
     } while (0)
-#define LCREC_STRIP4_LAUNCH(RSEL, KERN, cols, n, F, stream, ...)                                                       \
+#define LCREC_STRIP4_LAUNCH(KERN, MODE_, cols, n, F, stream, ...)                                                      \
     do {                                                                                                              \
         const dim3 grid_((unsigned)(((F) + (cols) - 1) / (cols)));                                                    \
-        if ((cols) == 32) RSEL(KERN, 32, n, grid_, stream, __VA_ARGS__);                                              \
-        else if ((cols) == 16) RSEL(KERN, 16, n, grid_, stream, __VA_ARGS__);                                         \
-        else RSEL(KERN, 8, n, grid_, stream, __VA_ARGS__);                                                            \
+        if ((cols) == 32) LCREC_STRIP4_R8(KERN, 32, MODE_, n, grid_, stream, __VA_ARGS__);                            \
+        else if ((cols) == 16) LCREC_STRIP4_R8(KERN, 16, MODE_, n, grid_, stream, __VA_ARGS__);                       \
+        else LCREC_STRIP4_R8(KERN, 8, MODE_, n, grid_, stream, __VA_ARGS__);                                          \
     } while (0)
 
 int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const float *beta, float eps, float momentum,
@@ -978,7 +1009,7 @@ int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const 
     TraceScope trace(K_BN_FWD, stream);
     const int v4 = strip4_cols(n, F, 8, {t, y, gamma, beta, running_mean, running_var, mean_out, rstd_out});
     if (v4) {
-        LCREC_STRIP4_LAUNCH(LCREC_STRIP4_R8, bn_relu_forward_v4_kernel, v4, n, F, stream, t, n, F, gamma, beta, eps, momentum, running_mean, running_var, y,
+        LCREC_STRIP4_LAUNCH(bn_relu_forward_v4_kernel, false, v4, n, F, stream, t, n, F, gamma, beta, eps, momentum, running_mean, running_var, y,
                             mean_out, rstd_out, relu);
         return check_launch("bn_relu_forward_v4_kernel");
     }
@@ -998,8 +1029,8 @@ int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n,
     TraceScope trace(K_BN_BWD, stream);
     const int v4 = strip4_cols(n, F, 8, {gy, t, y, gamma, mean, rstd, dt, dgamma, dbeta, dbias, fold_scale, fold_shift});
     if (v4) {
-        LCREC_STRIP4_LAUNCH(LCREC_STRIP4_R8, bn_relu_backward_v4_kernel, v4, n, F, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta,
-                            dbias, fold_scale, fold_shift);
+        const Bn4Bwd p{gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias, fold_scale, fold_shift, nullptr, nullptr, 0.f};
+        LCREC_STRIP4_LAUNCH(bn_relu_backward_v4_kernel, 0, v4, n, F, stream, p);
         return check_launch("bn_relu_backward_v4_kernel");
     }
     LCREC_STRIP_LAUNCH_N(bn_relu_backward_kernel, F, n, stream, gy, t, y, n, F, gamma, mean, rstd, relu, dt, dgamma, dbeta, dbias,
@@ -1012,6 +1043,12 @@ int bn_stats(const float *t, int64_t n, int F, float *mean_out, float *m2_out, h
     if (!t || !mean_out || !m2_out) return fail(LCREC_EINVAL, "bn_stats: NULL pointer");
     if (n < 1 || n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_stats: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_FWD, stream);
+    const int v4 = strip4_cols(n, F, 8, {t, mean_out, m2_out});
+    if (v4) {
+        LCREC_STRIP4_LAUNCH(bn_relu_forward_v4_kernel, true, v4, n, F, stream, t, n, F, (const float *)nullptr, (const float *)nullptr, 0.f, 0.f,
+                            (float *)nullptr, (float *)nullptr, (float *)nullptr, mean_out, m2_out, 0);
+        return check_launch("bn_relu_forward_v4_kernel<stats>");
+    }
     LCREC_STRIP_LAUNCH(bn_stats_kernel, F, stream, t, n, F, mean_out, m2_out);
     return check_launch("bn_stats_kernel");
 }
@@ -1045,6 +1082,12 @@ int bn_backward_reduce(const float *gy, const float *t, const float *y, int64_t 
     if (!gy || !t || !mean || !rstd || !sum_g || !sum_gx || (relu && !y)) return fail(LCREC_EINVAL, "bn_backward_reduce: NULL pointer");
     if (n < 1 || n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_backward_reduce: sized for training batches");
     TraceScope trace(K_BN_BWD, stream);
+    const int v4 = strip4_cols(n, F, 8, {gy, t, y, mean, rstd, sum_g, sum_gx, dbeta, dgamma});
+    if (v4) {
+        const Bn4Bwd p{gy, t, y, n, F, nullptr, mean, rstd, relu, nullptr, dgamma, dbeta, nullptr, nullptr, nullptr, sum_g, sum_gx, 0.f};
+        LCREC_STRIP4_LAUNCH(bn_relu_backward_v4_kernel, 1, v4, n, F, stream, p);
+        return check_launch("bn_relu_backward_v4_kernel<reduce>");
+    }
     LCREC_STRIP_LAUNCH(bn_backward_reduce_kernel, F, stream, gy, t, y, n, F, mean, rstd, relu, sum_g, sum_gx, dbeta, dgamma);
     return check_launch("bn_backward_reduce_kernel");
 }
@@ -1056,6 +1099,13 @@ int bn_backward_apply(const float *gy, const float *t, const float *y, int64_t n
     if (!gy || !t || !mean || !rstd || !sum_g || !sum_gx || !dt || (relu && !y)) return fail(LCREC_EINVAL, "bn_backward_apply: NULL pointer");
     if (n < 1 || n > (1 << 20) || F < 1 || !(n_total >= 1.0f)) return fail(LCREC_EUNSUPPORTED, "bn_backward_apply: sized for training batches");
     TraceScope trace(K_BN_BWD, stream);
+    const int v4 = strip4_cols(n, F, 8, {gy, t, y, gamma, mean, rstd, sum_g, sum_gx, dt, dbias});
+    if (v4) {
+        const Bn4Bwd p{gy, t, y, n, F, gamma, mean, rstd, relu, dt, nullptr, nullptr, dbias, nullptr, nullptr,
+                       const_cast<float *>(sum_g), const_cast<float *>(sum_gx), n_total};
+        LCREC_STRIP4_LAUNCH(bn_relu_backward_v4_kernel, 2, v4, n, F, stream, p);
+        return check_launch("bn_relu_backward_v4_kernel<apply>");
+    }
     LCREC_STRIP_LAUNCH(bn_backward_apply_kernel, F, stream, gy, t, y, n, F, gamma, mean, rstd, relu, sum_g, sum_gx, n_total, dt, dbias);
     return check_launch("bn_backward_apply_kernel");
 }

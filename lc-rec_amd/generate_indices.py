@@ -250,7 +250,7 @@ def recheck_neartie(state_dict, args, data, idx, resid_last, flags, batch_size=6
     new_idx, new_res = [], []
     for b in np.unique(flagged // batch_size):
         lo, hi = int(b) * batch_size, min(n, (int(b) + 1) * batch_size)
-        x = torch.from_numpy(np.ascontiguousarray(rows[lo:hi], dtype=np.float32))
+        x = torch.from_numpy(np.array(rows[lo:hi], dtype=np.float32))                 # a copy: the file may be a read-only memory map
         bi, br = reference_order_indices(sd, n_layers, bool(args.bn), levels, x)
         mine = flagged[(flagged >= lo) & (flagged < hi)] - lo
         new_idx.append(bi[mine])
