@@ -974,28 +974,33 @@ static int strip_cols(int F)
 // 16-byte alignment, or more rows than rmax per lane at the narrowest strip) -- then the dword kernels above run.
 static int strip4_cols(int64_t n, int F, int rmax, std::initializer_list<const void *> ptrs)
 {
-    static const int mode = [] { const char *e = getenv("LCREC_BN_V4"); return e ? atoi(e) : 16; }();   // 0 off; 8 / 32 force a strip width, 161 = 32 from 2048 columns (tuning)
+    static const int mode = [] { const char *e = getenv("LCREC_BN_V4"); return e ? atoi(e) : 1; }();   // 0 off; 4 / 8 / 16 force a strip width (tuning)
     if (!mode || (F & 3) || n * F >= ((int64_t)1 << 29)) return 0;       // 32-bit byte offsets inside the kernels
     for (const void *p : ptrs)
         if ((uintptr_t)p & 15) return 0;
-    // measured per call at 1024 rows (tools/bn_probe.py): backward 2048 columns 13.5 us at 16-column strips, 8.8 us at 32 (whole
-    // 128-byte lines per row); 1024 columns and fewer the same or better at 16 (more workgroups)
-    int cols = mode == 8 || mode == 32 ? mode : (mode == 161 && F >= 2048 ? 32 : 16);
-    while (cols > 8 && n > (int64_t)rmax * (CR_THREADS / (cols / 4))) cols /= 2;
+    // 16 columns (64-byte row segments) where that makes at least 32 strips; narrower strips for narrower layers, whose whole
+    // input is a few hundred KB that a handful of CUs would pull from memory one after the other (in the step the operands are
+    // cold: written by a GEMM on other XCDs, or a whole forward pass ago).  32-column strips: measured no better than 16 once
+    // the strips of an XCD are neighbours (tools/bn_probe.py).
+    int cols = mode == 4 || mode == 8 || mode == 16 ? mode : (F >= 512 ? 16 : (F >= 256 ? 8 : 4));
+    while (cols > 4 && n > (int64_t)rmax * (CR_THREADS / (cols / 4))) cols /= 2;
     return n <= (int64_t)rmax * (CR_THREADS / (cols / 4)) ? cols : 0;
 }
-// rows per lane: 4 or 8 by n
+// rows per lane: 1, 2, 4 or 8 by n
 #define LCREC_STRIP4_R8(KERN, COLS_, MODE_, n, grid_, stream, ...)                                                     \
     do {                                                                                                              \
-        if ((n) <= 4 * (CR_THREADS / (COLS_ / 4))) hipLaunchKernelGGL((KERN<COLS_, 4, MODE_>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); \
+        const int64_t rgs_ = CR_THREADS / (COLS_ / 4);                                                                \
+        if ((n) <= rgs_) hipLaunchKernelGGL((KERN<COLS_, 1, MODE_>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); \
+        else if ((n) <= 2 * rgs_) hipLaunchKernelGGL((KERN<COLS_, 2, MODE_>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); \
+        else if ((n) <= 4 * rgs_) hipLaunchKernelGGL((KERN<COLS_, 4, MODE_>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__); \
         else hipLaunchKernelGGL((KERN<COLS_, 8, MODE_>), grid_, dim3(CR_THREADS), 0, stream, __VA_ARGS__);             \
     } while (0)
 #define LCREC_STRIP4_LAUNCH(KERN, MODE_, cols, n, F, stream, ...)                                                      \
     do {                                                                                                              \
         const dim3 grid_((unsigned)(((F) + (cols) - 1) / (cols)));                                                    \
-        if ((cols) == 32) LCREC_STRIP4_R8(KERN, 32, MODE_, n, grid_, stream, __VA_ARGS__);                            \
-        else if ((cols) == 16) LCREC_STRIP4_R8(KERN, 16, MODE_, n, grid_, stream, __VA_ARGS__);                       \
-        else LCREC_STRIP4_R8(KERN, 8, MODE_, n, grid_, stream, __VA_ARGS__);                                          \
+        if ((cols) == 16) LCREC_STRIP4_R8(KERN, 16, MODE_, n, grid_, stream, __VA_ARGS__);                            \
+        else if ((cols) == 8) LCREC_STRIP4_R8(KERN, 8, MODE_, n, grid_, stream, __VA_ARGS__);                         \
+        else LCREC_STRIP4_R8(KERN, 4, MODE_, n, grid_, stream, __VA_ARGS__);                                          \
     } while (0)
 
 int bn_relu_forward(const float *t, int64_t n, int F, const float *gamma, const float *beta, float eps, float momentum,
