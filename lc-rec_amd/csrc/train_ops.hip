@@ -731,15 +731,25 @@ __global__ __launch_bounds__(RED_THREADS) void recon_loss_grad_kernel(const floa
     __shared__ int last_sh;
     const float scale = (l1 ? 1.0f : 2.0f) / (float)count_total;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < count; i += (int64_t)gridDim.x * RED_THREADS) {
-        const float d = out[i] - x[i];
-        if (l1) {
-            acc += (double)__builtin_fabsf(d);
-            if (g) g[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
-        } else {
-            acc += (double)d * (double)d;
-            if (g) g[i] = d * scale;
-        }
+    auto one = [&](float o, float t) {
+        const float d = o - t;
+        if (l1) { acc += (double)__builtin_fabsf(d); return d > 0.f ? scale : (d < 0.f ? -scale : 0.f); }
+        acc += (double)d * (double)d;
+        return d * scale;
+    };
+    // 16-byte accesses when the three arrays allow it (a lane's four elements in index order, so the workgroup's sum takes the
+    // elements in a fixed order either way); the ragged end and unaligned callers by scalars
+    const bool vec = (((uintptr_t)out | (uintptr_t)x | (uintptr_t)g) & 15) == 0;
+    const int64_t quads = vec ? count / 4 : 0;
+    for (int64_t q = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; q < quads; q += (int64_t)gridDim.x * RED_THREADS) {
+        const float4 o = reinterpret_cast<const float4 *>(out)[q], t = reinterpret_cast<const float4 *>(x)[q];
+        float4 r;
+        r.x = one(o.x, t.x); r.y = one(o.y, t.y); r.z = one(o.z, t.z); r.w = one(o.w, t.w);
+        if (g) reinterpret_cast<float4 *>(g)[q] = r;
+    }
+    for (int64_t i = quads * 4 + (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < count; i += (int64_t)gridDim.x * RED_THREADS) {
+        const float r = one(out[i], x[i]);
+        if (g) g[i] = r;
     }
     const double s = block_sum(acc, sm);
     if (!ticket) {
@@ -1125,9 +1135,9 @@ int relu_bias_backward(const float *gy, const float *y, int64_t n, int F, int re
     return check_launch("relu_bias_backward_kernel");
 }
 
-static int red_blocks(int64_t count)
+static int red_blocks(int64_t count, int per_thread = 16)
 {
-    int64_t b = (count + (int64_t)RED_THREADS * 16 - 1) / ((int64_t)RED_THREADS * 16);
+    int64_t b = (count + (int64_t)RED_THREADS * per_thread - 1) / ((int64_t)RED_THREADS * per_thread);
     return (int)(b < 1 ? 1 : (b > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : b));
 }
 
@@ -1141,7 +1151,7 @@ int recon_loss_grad(const float *out, const float *x, int64_t count, int64_t cou
     if (!out || !x || !loss) return fail(LCREC_EINVAL, "recon_loss_grad: NULL pointer");
     if (count < 1) return fail(LCREC_EINVAL, "recon_loss_grad: empty input");
     if (!workspace || workspace_bytes < train_reduce_workspace()) return fail(LCREC_EWORKSPACE, "recon_loss_grad: workspace too small");
-    const int blocks = red_blocks(count);
+    const int blocks = red_blocks(count, 4);          // one 16-byte access per lane and array: a batch's 786 k elements on 192 CUs, not 48
     TraceScope trace(K_LOSS, stream);
     hipLaunchKernelGGL(recon_loss_grad_kernel, dim3(blocks), dim3(RED_THREADS), 0, stream, out, x, count, count_total, l1, g, (double *)workspace,
                        ticket, loss);
