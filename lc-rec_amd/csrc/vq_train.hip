@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void vq_distance_kernel(const float *__restric
                     b = b2 > b ? b2 : b;
                 }
                 if (tid == 0) { minmax[0] = a; minmax[1] = b; }
-                if (tid >= 2 && tid < 8) minmax[tid] = 0u;            // barrier counter, timeout flag
+                if (tid >= 2 && tid < 32) minmax[tid] = 0u;           // barrier counter, timeout flag; [8] done, [16..31] XCD arrival counters
             }
             return;
         }
@@ -1042,7 +1042,48 @@ struct SkScale {
     double eps;
     int64_t *idx_out;
     int64_t idx_stride;
+    int replicas;          // > 1: the XCD-local form (below); part then holds `replicas` sets of buffers
+    unsigned *ranks;       // [16] arrival counters per XCC_ID, zero at launch
+    unsigned *done;        // set by the first workgroup to finish a solve
 };
+
+// ---- XCD-local exchange (replicas > 1).  The hand-over above is an agent-scope store (sc1: written through the XCD's L2 to the
+// memory side, because the eight L2s are not coherent with each other) and an agent-scope load that fetches it from there:
+// ~1 500 cycles per hop between XCDs, ~1 200 even when both workgroups sit on the same XCD.  Between two CUs of ONE XCD a plain
+// store (it stops in the shared L2) and an sc1 load (misses the CU's L1, hits that L2) take ~650 (tools/xcd_pingpong.hip: round
+// trips of 1 300 cycles against 2 400 / 3 050).  Workgroups are dealt to the XCDs round-robin, so a launch of 8 x nblk workgroups
+// puts nblk on each XCD -- and the solve is small enough to be done EIGHT times side by side on CUs that idle anyway: every XCD
+// runs the whole problem among its own workgroups, exchanging through its own L2, and all of them write the same assignments.
+// Nothing depends on the round-robin: a workgroup reads its XCC_ID, takes a rank from that XCD's arrival counter, and leaves if
+// the rank is beyond nblk; an XCD that got fewer than nblk never finishes an iteration, and its workgroups leave quietly once
+// any complete set has set `done` (they poll it while they wait).  Some XCD always gets at least nblk of 8 x nblk.
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u; }      // HW_REG_XCC_ID[3:0]
+
+__device__ __forceinline__ void skp_put_local(double *slot, unsigned long long bits)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// skp_take for the XCD-local form: as above, and a wait also ends -- quietly, nothing is flagged -- when another set has finished
+__device__ __forceinline__ double skp_take_local(const double *slot, unsigned long long first, unsigned *flag, const unsigned *done,
+                                                 bool &gave_up, bool &quiet)
+{
+    unsigned long long v = first;
+    unsigned spins = 0;
+    while (v == SKP_EMPTY) {
+        __builtin_amdgcn_s_sleep(1);
+        v = skp_peek(slot);
+        ++spins;
+        if (v == SKP_EMPTY && ((spins & 63u) == 0u)) {
+            if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; quiet = true; break; }
+            if (spins > SKP_SPIN_LIMIT || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+            }
+        }
+    }
+    return __builtin_bit_cast(double, v);
+}
 
 // Cross-lane moves of a double without the LDS crossbar.  row_partner<LEV>: the value of the lane this one is paired with at
 // level LEV inside its row of 16 lanes -- an involution that flips lane bit LEV (3: row_mirror, 2: row_half_mirror, 1 / 0:
@@ -1097,11 +1138,25 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
     const int K = p.K;
     double *colacc = sks_sm;                          // [SKP_WAVES][K]; after the publish: the gather buffer [split][K]
     double *bsh = sks_sm + (size_t)SKP_WAVES * K;     // [K] the new column scales
-    __shared__ int abort_sh;
+    __shared__ int abort_sh, bid_sh, set_sh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * ROWS + wave * RW;
-    if (threadIdx.x == 0) abort_sh = 0;
-    bool gave_up = false;
+    const bool local = p.replicas > 1;
+    if (threadIdx.x == 0) {
+        abort_sh = 0;
+        bid_sh = (int)blockIdx.x;
+        set_sh = 0;
+        if (local) {
+            const unsigned x = xcc_id();
+            set_sh = (int)x;
+            bid_sh = (int)__hip_atomic_fetch_add(p.ranks + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    const int bid = bid_sh;
+    if (bid >= p.nblk || set_sh >= p.replicas) return;        // more than nblk on this XCD: not needed
+    double *const part = p.part + (size_t)set_sh * 3 * p.nblk * p.K;
+    const int64_t row0 = (int64_t)bid * ROWS + wave * RW;
+    bool gave_up = false, quiet = false;
     const double Bd = (double)p.B, Kd = (double)K;
     const float hi = ord2f(p.minmax[1]), lo = ord2f(p.minmax[0]);
     const float middle = (hi + lo) / 2.0f;
@@ -1132,8 +1187,11 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
     for (int it = 0; it < p.iters; ++it) {
         SK_STAMP(7);
         if (it >= 2) {                                           // re-arm the buffer of the NEXT iteration (it carried it - 2)
-            double *arm = p.part + ((size_t)((it + 1) % 3) * p.nblk + blockIdx.x) * K;
-            for (int j = threadIdx.x; j < K; j += SKP_THREADS) skp_put(arm + j, SKP_EMPTY);
+            double *arm = part + ((size_t)((it + 1) % 3) * p.nblk + bid) * K;
+            for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
+                if (local) skp_put_local(arm + j, SKP_EMPTY);
+                else skp_put(arm + j, SKP_EMPTY);
+            }
         }
         // row scales a_i = 1 / (B * sum_j E_ij b_j).  The RW row sums of a wave are reduced TOGETHER, in registers: inside each
         // row of 16 lanes LOG_RW halving exchanges (lanes with the level's bit set keep the upper half of the values, the
@@ -1183,17 +1241,18 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
         }
         __syncthreads();
         SK_STAMP(1);
-        double *out = p.part + ((size_t)(it % 3) * p.nblk + blockIdx.x) * K;
+        double *out = part + ((size_t)(it % 3) * p.nblk + bid) * K;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the re-arming stores have reached memory
         for (int j = threadIdx.x; j < K; j += SKP_THREADS) {
             double t = 0.0;
             for (int w = 0; w < SKP_WAVES; ++w) t += colacc[w * K + j];
-            skp_put(out + j, __builtin_bit_cast(unsigned long long, t));
+            if (local) skp_put_local(out + j, __builtin_bit_cast(unsigned long long, t));
+            else skp_put(out + j, __builtin_bit_cast(unsigned long long, t));
         }
         __syncthreads();                                         // colacc has been read: it is the gather buffer now
         SK_STAMP(2);
         // every workgroup's partial of every column, added in workgroup order (chunk by chunk when several threads share a column)
-        const double *src = p.part + (size_t)(it % 3) * p.nblk * K;
+        const double *src = part + (size_t)(it % 3) * p.nblk * K;
         for (int i = threadIdx.x; i < K * split; i += SKP_THREADS) {
             const int j = i % K, h = i / K;
             const int b0 = h * chunk, b1 = b0 + chunk < p.nblk ? b0 + chunk : p.nblk;
@@ -1205,11 +1264,13 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
                     if (bb + u < b1) v[u] = skp_peek(src + (size_t)(bb + u) * K + j);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (bb + u < b1) t += skp_take(src + (size_t)(bb + u) * K + j, v[u], p.flag, gave_up);
+                    if (bb + u < b1)
+                        t += local ? skp_take_local(src + (size_t)(bb + u) * K + j, v[u], p.flag, p.done, gave_up, quiet)
+                                   : skp_take(src + (size_t)(bb + u) * K + j, v[u], p.flag, gave_up);
             }
             colacc[h * K + j] = t;
         }
-        if (gave_up) abort_sh = 1;
+        if (gave_up) abort_sh = quiet ? 2 : 1;
         SK_STAMP(3);
         __syncthreads();
         SK_STAMP(4);
@@ -1227,6 +1288,7 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
         SK_STAMP(5);
         if (abort_sh) break;                                     // uniform: read after a barrier every thread passed
     }
+    if (abort_sh == 2) return;                                   // another XCD's set finished the solve: it writes the assignments
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         double best = -1.0;
@@ -1250,6 +1312,9 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
             p.idx_out[(row0 + r) * p.idx_stride] = bad ? -1 : bj;
         }
     }
+    // (a workgroup that got here has seen every member of its set publish the last iteration: the set is complete and all of it
+    // will write its rows; incomplete sets may stop waiting)
+    if (local && threadIdx.x == 0) __hip_atomic_store(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 static size_t sks_lds_bytes(int K) { return (size_t)(SKP_WAVES + 1) * K * sizeof(double); }
@@ -1271,7 +1336,7 @@ static bool launch_sks(const SkScale &p, hipStream_t stream)
             granted = lds;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk), dim3(SKP_THREADS), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nblk * (p.replicas > 1 ? p.replicas : 1))), dim3(SKP_THREADS), lds, stream, p);
     return true;
 }
 
@@ -1325,7 +1390,7 @@ static bool launch_skp(const SkPersist &p, hipStream_t stream)
 // solver, the sentinels of its exchange slots (`count` doubles; nothing inside that kernel orders "armed" before the first poll)
 __global__ __launch_bounds__(256) void sk_ctrl_init_kernel(unsigned *ctrl, double *slots, int64_t count)
 {
-    if (blockIdx.x == 0 && threadIdx.x < 8) ctrl[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 32) ctrl[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
         reinterpret_cast<unsigned long long *>(slots)[i] = SKP_EMPTY;
 }
@@ -1362,7 +1427,10 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
     // (engine.py) the two memsets were seen to take effect late -- replays found the previous solve's flag / a counter reset
     // under a running barrier
     // With a ticket the distance launch does all of that itself (its last workgroup writes the control words).
-    const int64_t slot_count = scaling ? (int64_t)3 * nblk_s * K : (int64_t)0;
+    // XCD-local exchange (sk_scaling_kernel): eight sets of buffers when they fit the region.  LCREC_SK_LOCAL=0: one set, agent scope.
+    static const bool allow_local = [] { const char *e = getenv("LCREC_SK_LOCAL"); return !e || atoi(e) != 0; }();
+    const int replicas = scaling && allow_local && (int64_t)8 * 3 * nblk_s <= B && 8 * nblk_s <= 256 ? 8 : 1;
+    const int64_t slot_count = scaling ? (int64_t)replicas * 3 * nblk_s * K : (int64_t)0;
     const int64_t dist_blocks = ((B + DIST_ITEMS - 1) / DIST_ITEMS) * ((K + 255) / 256);
     int rc;
     if (ticket && dist_blocks <= DIST_TICKET_MAX_BLOCKS) {
@@ -1381,6 +1449,7 @@ static int sinkhorn_big(const float *r, int64_t B, int e, const float *cb, int K
         q.d = d; q.part = p.Q; q.minmax = minmax; q.flag = minmax + 5;
         q.B = B; q.K = K; q.nblk = (int)nblk_s; q.iters = iters; q.eps = eps;
         q.idx_out = idx_out; q.idx_stride = idx_stride;
+        q.replicas = replicas; q.done = minmax + 8; q.ranks = minmax + 16;
         bool launched;
         if (cpl_t == 1) launched = launch_sks_rw<1>(q, rw, stream);
         else if (cpl_t == 2) launched = launch_sks_rw<2>(q, rw, stream);
