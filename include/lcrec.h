@@ -35,10 +35,14 @@
  *       LCREC_GEMM_SPLITK           cap on the K-runs of the weight gradient (changes S of
  *                                  lcrec_linear_backward_splits, hence its documented sum)
  *       LCREC_RQ_SPLIT              the batch-sized form of lcrec_rq_assign
- *       LCREC_SINKHORN_SCALING, LCREC_SINKHORN_PERSISTENT, LCREC_SK_RW, LCREC_SK_BLOCKS
- *                                  which batch-sized Sinkhorn solver runs (assignments may
- *                                  differ only inside the 1e-9 margin stated at the call)
- *       LCREC_STRIP_COLS            strip width of the BatchNorm column reductions
+ *       LCREC_SINKHORN_SCALING, LCREC_SINKHORN_PERSISTENT, LCREC_SK_RW, LCREC_SK_BLOCKS,
+ *       LCREC_SK_LOCAL              which batch-sized Sinkhorn solver runs, and whether its
+ *                                  exchange stays inside one XCD (assignments may differ only
+ *                                  inside the 1e-9 margin stated at the call)
+ *       LCREC_STRIP_COLS, LCREC_BN_V4, LCREC_BN_CACHED_MIN
+ *                                  strip width / kernel form of the BatchNorm column reductions
+ *                                  (the forms sum a column's rows in different orders: last-bit
+ *                                  differences in the statistics, within the stated tolerances)
  *     A deployment sets none of them; being process-global they are outside the
  *     per-call / per-context contract above;
  *   - return 0 on success, a negative LCREC_E* code otherwise; the message for
