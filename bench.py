@@ -280,6 +280,9 @@ def main():
     ap.add_argument("--items", type=int, default=0, help="override items per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the quantizer-only and training-step figures (N=1 only)")
+    ap.add_argument("--trace-pass", choices=["auto", "timed", "separate"], default="auto",
+                    help="where the per-launch hipEvent brackets behind `roofline` are taken: inside the timed region (default), or "
+                         "in an untimed pass of the same launches right after it (default for --workload c2, whose launches are short)")
     ap.add_argument("--pipelines", type=int, default=0,
                     help="chunk pipelines of lcrec_encode_assign (lcrec_context_set_pipelines); 0 = the library's default (1)")
     ap.add_argument("--rehearse-rccl", action="store_true",
@@ -347,7 +350,12 @@ def main():
     for _ in range(args.warmup):
         idx = step()
     barrier()
-    ops.trace_enable(True)
+    # The hipEvent pair around every launch is itself stream work (two marker packets per launch).  At C3 -- 15 launches of
+    # 0.1-20 ms per pass -- that is nothing; at C2 a pass is 11 launches in 2.7 ms and the markers cost it ~4 % (measured:
+    # --trace-pass timed vs separate).  "separate" keeps the timed region free of them and brackets the same launches in an
+    # untimed pass right after it (the default for c2 only; the headline workloads are bracketed inside the timed region).
+    trace_pass = args.trace_pass if args.trace_pass != "auto" else ("separate" if args.workload == "c2" else "timed")
+    ops.trace_enable(trace_pass == "timed")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         idx = step()
@@ -360,8 +368,8 @@ def main():
     # untimed pass with ONE pipeline (same inputs, same launches, nothing overlapped); the in-region figures are kept
     # next to it.  `python bench.py --pipelines 1` makes the two coincide (that is the command profiled for profiles/).
     solo_trace, solo_steps = None, 0
-    if pipelines > 1:
-        solo_steps = min(args.steps, 3)
+    if pipelines > 1 or trace_pass == "separate":
+        solo_steps = min(args.steps, 3) if pipelines > 1 else args.steps
         ops.set_pipelines(1)
         step()
         barrier()
@@ -444,7 +452,10 @@ def main():
         ach = fl / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
         return launches, total_ms, fl, ach
 
-    in_launches, in_ms, in_flops, in_ach = kernel_rate(trace, args.steps)
+    separate = trace_pass == "separate" and pipelines == 1
+    if separate:
+        trace = solo_trace                      # the timed region carried no brackets: every per-kernel figure is the untimed pass's
+    in_launches, in_ms, in_flops, in_ach = kernel_rate(trace, solo_steps if separate else args.steps)
     launches, total_ms, flops_dom_total, achieved = kernel_rate(solo_trace, solo_steps) if solo_trace else \
         (in_launches, in_ms, in_flops, in_ach)
     traffic = None
@@ -461,6 +472,9 @@ def main():
         "flops_per_launch": (flops_dom_total / launches) if launches else None,
         "algorithmic_bytes_per_launch": (alg_bytes[dom] / in_launches) if in_launches else None,
         "measured": ("hipEvent pairs around every launch of the kernel, in the timed region" if not solo_trace else
+                     f"hipEvent pairs around every launch of the kernel in an untimed pass of {solo_steps} steps right after the timed "
+                     f"region (same inputs, same launches); the timed region carries no brackets (--trace-pass separate: at this "
+                     f"workload the marker packets cost the pass ~4 %)" if separate else
                      f"hipEvent pairs around every launch of the kernel in an untimed pass of {solo_steps} steps with one chunk "
                      f"pipeline; the timed region runs {pipelines} pipelines whose launches overlap (see in_region)"),
         "in_region": {"pipelines": pipelines, "launches": in_launches,

@@ -465,11 +465,14 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     if (e != 16 && e != 32 && e != 64) return fail(LCREC_EUNSUPPORTED, "rq_assign: e_dim=%d (supported: 16, 32, 64)", e);
     if (((uintptr_t)z | (uintptr_t)codebooks | (uintptr_t)xq_out | (uintptr_t)resid_out) & 15)
         return fail(LCREC_EINVAL, "rq_assign: buffers must be 16-byte aligned");
-    // batch-sized inputs (at most 64 tiles of 64 items) with enough code blocks to deal out: the split form (see the kernel)
+    // batch-sized inputs with enough code blocks to deal out: the split form (see the kernel).  Up to 512 tiles of 64 items: below
+    // that the one-tile-per-wave form leaves most CUs without a wave while each wave walks its tile's levels alone (Games' 16 859
+    // items: 264 tiles on 66 workgroups, 55 us; LCREC_RQ_SPLIT_TILES, tuning)
+    static const int64_t split_tiles = [] { const char *v = getenv("LCREC_RQ_SPLIT_TILES"); return (int64_t)(v ? atoi(v) : 512); }();
     int max_k = 0;
     for (int l = 0; l < L; ++l) max_k = K[l] > max_k ? K[l] : max_k;
     static const bool allow_split = [] { const char *v = getenv("LCREC_RQ_SPLIT"); return !v || atoi(v) != 0; }();
-    bool split = allow_split && n > 0 && (n + 63) / 64 <= 64 && max_k >= 128;
+    bool split = allow_split && n > 0 && (n + 63) / 64 <= split_tiles && max_k >= 128;
     for (int l = 0; split && l < L; ++l)       // (its hand-over buffers must not push a level out of LDS that fits without them)
         if (K[l] > 0 && lds_bytes((K[l] + 31) & ~31, e, L, 4, true) > LDS_BUDGET) split = false;
     const int threads = split ? 256 : threads_for(e, n);
@@ -487,7 +490,9 @@ int rq_assign(const float *z, int64_t n, int e, const float *codebooks, const in
     float *ping = reinterpret_cast<float *>(workspace);
     float *pong = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + resid_bytes);
     double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 2 * resid_bytes);
-    const int grid = split ? (int)((n + 63) / 64) : grid_for(n, threads);
+    // (split: the staged codebooks leave room for one workgroup per CU, so more than MAX_GRID of them would run in rounds and
+    // stage again; the tile loop takes the rest)
+    const int grid = split ? (int)((n + 63) / 64 < MAX_GRID ? (n + 63) / 64 : MAX_GRID) : grid_for(n, threads);
 
     // Greedily pack consecutive levels into launches whose codebooks fit in LDS.
     int64_t cb_offs[LCREC_MAX_LEVELS];

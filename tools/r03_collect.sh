@@ -4,7 +4,11 @@ set -u
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/r03; mkdir -p $o
 python bench.py --steps 20 --warmup 5 > $o/bench_c3.json 2> $o/bench_c3.err; echo "bench c3 rc=$?"
-for w in c2 c4 c5; do python bench.py --workload $w --steps 10 --warmup 3 > $o/bench_$w.json 2> $o/bench_$w.err; echo "bench $w rc=$?"; done
+# (c2: a pass is 2.7 ms -- 40 of them; its per-launch brackets are taken in an untimed pass, bench.py --trace-pass; the same command with
+#  --trace-pass timed beside it shows what the marker packets cost)
+python bench.py --workload c2 --steps 40 --warmup 10 > $o/bench_c2.json 2> $o/bench_c2.err; echo "bench c2 rc=$?"
+python bench.py --workload c2 --steps 40 --warmup 10 --trace-pass timed --no-cpu-baseline --no-secondary > $o/bench_c2_timed_brackets.json 2> $o/bench_c2_timed.err; echo "bench c2 (brackets in the timed region) rc=$?"
+for w in c4 c5; do python bench.py --workload $w --steps 10 --warmup 3 > $o/bench_$w.json 2> $o/bench_$w.err; echo "bench $w rc=$?"; done
 # the training step: run.sh recipe (bn=True, batch 1024) at 768-d and 4096-d, batch 2048, bn=False; fused-BatchNorm opt-in; one-rank RCCL group
 {
 for args in "--batch 1024 --bn" "--batch 1024" "--batch 2048 --bn" "--batch 1024 --bn --in_dim 4096" "--batch 2048 --bn --in_dim 4096" "--batch 1024 --bn --rccl1"; do
