@@ -1063,28 +1063,6 @@ __device__ __forceinline__ void skp_put_local(double *slot, unsigned long long b
 {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// skp_take for the XCD-local form: as above, and a wait also ends -- quietly, nothing is flagged -- when another set has finished
-__device__ __forceinline__ double skp_take_local(const double *slot, unsigned long long first, unsigned *flag, const unsigned *done,
-                                                 bool &gave_up, bool &quiet)
-{
-    unsigned long long v = first;
-    unsigned spins = 0;
-    while (v == SKP_EMPTY) {
-        __builtin_amdgcn_s_sleep(1);
-        v = skp_peek(slot);
-        ++spins;
-        if (v == SKP_EMPTY && ((spins & 63u) == 0u)) {
-            if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; quiet = true; break; }
-            if (spins > SKP_SPIN_LIMIT || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gave_up = true;
-                break;
-            }
-        }
-    }
-    return __builtin_bit_cast(double, v);
-}
-
 // Cross-lane moves of a double without the LDS crossbar.  row_partner<LEV>: the value of the lane this one is paired with at
 // level LEV inside its row of 16 lanes -- an involution that flips lane bit LEV (3: row_mirror, 2: row_half_mirror, 1 / 0:
 // quad permutes), which is all a sum reduction needs.  swap16_sum / swap32_sum: v + (v of the lane 16 / 32 away), by the gfx950
@@ -1258,15 +1236,35 @@ __global__ __launch_bounds__(SKP_THREADS) void sk_scaling_kernel(SkScale p)
             const int b0 = h * chunk, b1 = b0 + chunk < p.nblk ? b0 + chunk : p.nblk;
             double t = 0.0;
             for (int bb = b0; bb < b1; bb += 8) {                // eight polls in flight, then the adds in order
+                // Every round re-polls ALL slots that were still empty, side by side.  (First form: after the eight first polls,
+                // each empty slot was waited for on its own, one load in flight -- the workgroups publish at about the same time,
+                // so all eight are usually empty at the first poll, and the second slot's wait only started when the first's
+                // ended: up to eight dependent round trips where one or two do.)
                 unsigned long long v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (bb + u < b1) v[u] = skp_peek(src + (size_t)(bb + u) * K + j);
+                for (int u = 0; u < 8; ++u) v[u] = bb + u < b1 ? skp_peek(src + (size_t)(bb + u) * K + j) : 0ull;
+                unsigned spins = 0;
+                for (;;) {
+                    bool pending = false;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pending = pending || v[u] == SKP_EMPTY;
+                    if (!pending) break;
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (v[u] == SKP_EMPTY) v[u] = skp_peek(src + (size_t)(bb + u) * K + j);
+                    if ((++spins & 63u) == 0u) {
+                        if (local && __hip_atomic_load(p.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; quiet = true; break; }
+                        if (spins > SKP_SPIN_LIMIT || __hip_atomic_load(p.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                            __hip_atomic_store(p.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gave_up = true;
+                            break;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (bb + u < b1)
-                        t += local ? skp_take_local(src + (size_t)(bb + u) * K + j, v[u], p.flag, p.done, gave_up, quiet)
-                                   : skp_take(src + (size_t)(bb + u) * K + j, v[u], p.flag, gave_up);
+                    if (bb + u < b1) t += __builtin_bit_cast(double, v[u]);
             }
             colacc[h * K + j] = t;
         }
