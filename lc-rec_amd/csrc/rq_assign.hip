@@ -90,19 +90,34 @@ __global__ __launch_bounds__(THREADS) void rq_assign_kernel(RqParams p)
     for (int l = p.l0; l < p.l1; ++l) {
       const int kpad = (p.K[l] + 31) & ~31;
       const float *lsrc = p.cb + p.cb_off[l];
-      for (int q = tid; q < kpad * (E / 8); q += THREADS) {
-        const int lrow = q / (E / 8), g = q % (E / 8);
-        const int row = p.row_off[l] + lrow;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-        if (lrow < p.K[l]) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(lsrc + (size_t)lrow * E + g * 8);
-            a = src[0];
-            b = src[1];
+      // Four trips' loads issued before the first LDS write, unconditionally (padding rows read row 0 and are zeroed): a
+      // batch-sized launch is one tile per workgroup, and the 12 trips of this loop at 3 x 256 codes were 12 dependent memory round
+      // trips before the first MFMA.
+      const int total = kpad * (E / 8);
+      for (int q0 = tid; q0 < total; q0 += 4 * THREADS) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * THREADS;
+            const int lrow = q < total ? q / (E / 8) : 0, g = q % (E / 8);
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(lsrc + (size_t)(lrow < p.K[l] ? lrow : 0) * E + g * 8);
+            a[u] = src[0];
+            b[u] = src[1];
         }
-        f32x4 ev = {a[0], a[2], b[0], b[2]};
-        f32x4 od = {a[1], a[3], b[1], b[3]};
-        *reinterpret_cast<f32x4 *>(cbs + row * S + g * 4) = ev;
-        *reinterpret_cast<f32x4 *>(cbs + row * S + H + g * 4) = od;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * THREADS;
+            if (q >= total) break;
+            const int lrow = q / (E / 8), g = q % (E / 8);
+            const int row = p.row_off[l] + lrow;
+            const bool real = lrow < p.K[l];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 av = real ? a[u] : zero, bv = real ? b[u] : zero;
+            f32x4 ev = {av[0], av[2], bv[0], bv[2]};
+            f32x4 od = {av[1], av[3], bv[1], bv[3]};
+            *reinterpret_cast<f32x4 *>(cbs + row * S + g * 4) = ev;
+            *reinterpret_cast<f32x4 *>(cbs + row * S + H + g * 4) = od;
+        }
       }
     }
     for (int q = tid; q < WAVES * p.L; q += THREADS) wave_sse[q] = 0.0;

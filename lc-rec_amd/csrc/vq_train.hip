@@ -84,18 +84,24 @@ __global__ __launch_bounds__(256) void vq_distance_kernel(const float *__restric
     }
     __syncthreads();
     float lo = __builtin_inff(), hi = -__builtin_inff();
-    for (int t = 0; t < DIST_ITEMS; ++t) {
-        const int64_t i = i0 + t;
-        if (i >= n) break;
-        float dot = 0.f;
+    // four items' chains side by side (each its own k-ascending fma chain, the same bits): one wave per SIMD here, and a single
+    // chain of 32 dependent fmas per item left the ALU waiting on itself
+    for (int t0 = 0; t0 < DIST_ITEMS && i0 + t0 < n; t0 += 4) {
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < E; ++k) dot = __builtin_fmaf(rs[t][k], c[k], dot);
-        const float s = xs[t] + cc;
-        const float dv = __builtin_fmaf(-2.0f, dot, s);
-        if (j < K) {
-            d[i * K + j] = dv;
-            lo = dv < lo ? dv : lo;
-            hi = dv > hi ? dv : hi;
+        for (int k = 0; k < E; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dot[u] = __builtin_fmaf(rs[t0 + u][k], c[k], dot[u]);      // rows past n hold zeros
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + t0 + u;
+            const float s = xs[t0 + u] + cc;
+            const float dv = __builtin_fmaf(-2.0f, dot[u], s);
+            if (j < K && i < n) {
+                d[i * K + j] = dv;
+                lo = dv < lo ? dv : lo;
+                hi = dv > hi ? dv : hi;
+            }
         }
     }
     if (minmax) {
