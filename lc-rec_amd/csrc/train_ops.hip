@@ -268,7 +268,8 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const floa
 // lanes wide and RGS = 1024 / (COLS / 4) row groups deep, so a 1024 x 16 strip is FOUR 16-byte loads per lane and array, all in
 // flight at once, where the dword form above issues 16 per lane -- on one CU the dword form is bound by the texture-address
 // rate (13 us for a 1024 x 16 backward strip however few strips the launch has; r03 kernel trace by grid size).
-// Row order of the sums: lane rows ascending, then the xor tree over the wave's row groups, then the 16 waves in order.
+// Row order of the sums (fixed, so the same bits on every run): a lane's rows ascending; the row groups of a 16-lane row by DPP
+// rotations; the workgroup's 64 such rows as four chains of 16 in row order, ((c0 + c1) + (c2 + c3)) -- see sum() below.
 template <int COLS>
 struct Strip4 {
     static constexpr int L4 = COLS / 4, RGS = CR_THREADS / L4;
