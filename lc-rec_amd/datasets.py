@@ -66,16 +66,18 @@ class EmbDataset(data.Dataset):
                     done[i % ring].synchronize()         # the H2D copy that last read this buffer has finished
                 np.copyto(stage[i % ring][:hi - lo].numpy(), src[first + lo:first + hi], casting="unsafe")
 
-            with cf.ThreadPoolExecutor(max_workers=workers) as pool:
-                fills = {i: pool.submit(fill, i, False) for i in range(min(ring, len(chunks)))}
-                for i, (lo, hi) in enumerate(chunks):
-                    fills.pop(i).result()
-                    with torch.cuda.stream(copier):
-                        out[lo:hi].copy_(stage[i % ring][:hi - lo], non_blocking=True)
-                        done[i % ring].record(copier)
-                    if i + ring < len(chunks):           # its buffer's event is recorded now: safe to hand to a worker
-                        fills[i + ring] = pool.submit(fill, i + ring, True)
-            copier.synchronize()
+            try:
+                with cf.ThreadPoolExecutor(max_workers=workers) as pool:
+                    fills = {i: pool.submit(fill, i, False) for i in range(min(ring, len(chunks)))}
+                    for i, (lo, hi) in enumerate(chunks):
+                        fills.pop(i).result()
+                        with torch.cuda.stream(copier):
+                            out[lo:hi].copy_(stage[i % ring][:hi - lo], non_blocking=True)
+                            done[i % ring].record(copier)
+                        if i + ring < len(chunks):       # its buffer's event is recorded now: safe to hand to a worker
+                            fills[i + ring] = pool.submit(fill, i + ring, True)
+            finally:
+                copier.synchronize()                     # (also on an error: no copy may still read a staging buffer when it is freed)
             torch.cuda.current_stream(device).wait_stream(copier)
         if whole:
             self._device_copy = out
