@@ -349,7 +349,9 @@ int lcrec_bn_relu_forward(const float *t, int64_t n, int features, const float *
  * dt = gamma*rstd*(g - dbeta/n - xhat*dgamma/n);  dbias = sum dt -- the gradient of the Linear bias feeding the
  * BatchNorm (zero up to rounding, as in the reference).  dgamma/dbeta/dbias may be NULL; dt may alias gy.
  * y may be NULL when relu != 0 and fold_scale / fold_shift [features] are given: the mask is then [t * fold_scale +
- * fold_shift > 0] (one fma), the expression the consumer of lcrec_linear_bn_forward's output evaluated. */
+ * fold_shift > 0] (one fma), the expression the consumer of lcrec_linear_bn_forward's output evaluated.  With y NULL,
+ * fold_scale NULL and fold_shift = the layer's beta [features], the mask is [(t - mean) * rstd * gamma + beta > 0]
+ * evaluated exactly as lcrec_bn_relu_forward evaluates y: the same bits as passing that y, one array less to read. */
 int lcrec_bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n, int features, const float *gamma,
                            const float *mean, const float *rstd, int relu, float *dt_out, float *dgamma_out,
                            float *dbeta_out, float *dbias_out, const float *fold_scale, const float *fold_shift, void *stream);

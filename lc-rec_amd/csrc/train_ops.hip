@@ -202,12 +202,16 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_kernel(const floa
     const float mu = mean[col], rs = rstd[col], gm = gamma ? gamma[col] : 1.0f;
     const float *gc = gy + col, *tc = t + col, *yc = (relu && y) ? y + col : nullptr;
     // the ReLU mask from the stored activation y, or -- when the forward never wrote one (lcrec_linear_bn_forward hands t to the
-    // next layer, which applies max(t * scale + shift, 0) itself) -- from the same fused expression the consumer evaluated
-    const float fs = (relu && !y) ? fold_scale[col] : 0.f, fh = (relu && !y) ? fold_shift[col] : 0.f;
+    // next layer, which applies max(t * scale + shift, 0) itself) -- from the same fused expression the consumer evaluated; or,
+    // with fold_shift alone (= beta), from lcrec_bn_relu_forward's own expression (t - mean) * rstd * gamma + beta: the bits of
+    // the y it wrote, without reading it
+    const bool from_beta = relu && !y && !fold_scale;
+    const float fs = (relu && !y && fold_scale) ? fold_scale[col] : 0.f, fh = (relu && !y) ? fold_shift[col] : 0.f;
     auto gval = [&](int64_t r) {
         float g = gc[r * F];
         if (relu) {
-            const bool on = yc ? yc[r * F] > 0.f : __builtin_fmaf(tc[r * F], fs, fh) > 0.f;
+            const bool on = yc ? yc[r * F] > 0.f
+                               : (from_beta ? (tc[r * F] - mu) * rs * gm + fh > 0.f : __builtin_fmaf(tc[r * F], fs, fh) > 0.f);
             if (!on) g = 0.f;
         }
         return g;
@@ -457,8 +461,11 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_v4_kernel(Bn4Bwd 
     ld4(mu, p.mean + col);
     ld4(rs, p.rstd + col);
     if (MODE != 1 && p.gamma) ld4(gm, p.gamma + col);
-    const bool from_y = relu && y, from_fold = relu && !y;     // the ReLU mask: stored activation, or the consumer's fused expression
-    if (from_fold) { ld4(fs, p.fold_scale + col); ld4(fh, p.fold_shift + col); }
+    // the ReLU mask: the stored activation; or the consumer's fused expression fma(t, fold_scale, fold_shift); or, with fold_shift
+    // alone (= beta), the forward's own expression -- the bits of the y it wrote, one array less to read (in the step: 2 us a call)
+    const bool from_y = relu && y, from_fold = relu && !y && p.fold_scale, from_beta = relu && !y && !p.fold_scale;
+    if (from_fold) ld4(fs, p.fold_scale + col);
+    if (from_fold || from_beta) ld4(fh, p.fold_shift + col);
     float gv[RMAX][4], xv[RMAX][4];               // the lane's masked gradients and xhat, read once
 #pragma unroll
     for (int u = 0; u < RMAX; ++u) {
@@ -476,9 +483,10 @@ __global__ __launch_bounds__(CR_THREADS) void bn_relu_backward_v4_kernel(Bn4Bwd 
             if (from_y) ld4(yy, y + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool on = from_fold ? __builtin_fmaf(tt[e], fs[e], fh[e]) > 0.f : yy[e] > 0.f;
+                const float xh = (tt[e] - mu[e]) * rs[e];
+                const bool on = from_fold ? __builtin_fmaf(tt[e], fs[e], fh[e]) > 0.f : (from_beta ? xh * gm[e] + fh[e] > 0.f : yy[e] > 0.f);
                 gv[u][e] = (in && on) ? gv[u][e] : 0.f;
-                xv[u][e] = in ? (tt[e] - mu[e]) * rs[e] : 0.f;
+                xv[u][e] = in ? xh : 0.f;
             }
         } else {
 #pragma unroll
@@ -1060,8 +1068,8 @@ int bn_relu_backward(const float *gy, const float *t, const float *y, int64_t n,
                      const float *fold_shift, hipStream_t stream)
 {
     if (n == 0 || F == 0) return LCREC_OK;
-    if (!gy || !t || !mean || !rstd || !dt || (relu && !y && !(fold_scale && fold_shift)))
-        return fail(LCREC_EINVAL, "bn_relu_backward: NULL pointer (with relu: y, or fold_scale and fold_shift)");
+    if (!gy || !t || !mean || !rstd || !dt || (relu && !y && !fold_shift))
+        return fail(LCREC_EINVAL, "bn_relu_backward: NULL pointer (with relu: y, or fold_scale and fold_shift, or fold_shift = beta alone)");
     if (n > (1 << 20) || F < 1) return fail(LCREC_EUNSUPPORTED, "bn_relu_backward: sized for training batches (n=%lld)", (long long)n);
     TraceScope trace(K_BN_BWD, stream);
     const int v4 = strip4_cols(n, F, 8, {gy, t, y, gamma, mean, rstd, dt, dgamma, dbeta, dbias, fold_scale, fold_shift});

@@ -236,9 +236,12 @@ class TrainEngine:
                 dt, _ = ops.bn_backward_apply(g, t, y, bn.weight.data, mean, rstd, sums, self.dist.batch_rows[1], relu,
                                               dbias_out=gv[lin.bias])
             elif bn is not None:
-                dt, _, _, _ = ops.bn_relu_backward(g, t, y, bn.weight.data, mean, rstd, relu, dgamma_out=gv[bn.weight],
-                                                   dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias],
-                                                   fold=None if y is not None else out_fold[:2])
+                # (the ReLU mask is recomputed from t with the forward kernel's own expression: y is not read again)
+                recompute = relu and y is not None and bn.bias is not None
+                dt, _, _, _ = ops.bn_relu_backward(g, t, None if recompute else y, bn.weight.data, mean, rstd, relu,
+                                                   dgamma_out=gv[bn.weight], dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias],
+                                                   fold=None if y is not None else out_fold[:2],
+                                                   beta=bn.bias.data if recompute else None)
             else:
                 dt, _ = ops.relu_bias_backward(g, y, relu, dbias_out=gv[lin.bias], inplace=True)
             dw.append((dt, h, gv[lin.weight]) if in_fold is None else (dt, h, gv[lin.weight], in_fold))

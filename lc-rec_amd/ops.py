@@ -691,10 +691,11 @@ def bn_relu_forward(t, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, r
     return y, mean, rstd
 
 
-def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, dbeta_out=None, dbias_out=None, fold=None):
+def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, dbeta_out=None, dbias_out=None, fold=None, beta=None):
     """(dt, dgamma, dbeta, dbias) of y = [relu](bn(t)) for gy = dL/dy (see lcrec_bn_relu_backward); the three vector
     outputs may be given (views of a flat gradient buffer).  y None + fold = (scale, shift): the ReLU mask is recomputed as
-    [t * scale + shift > 0]."""
+    [t * scale + shift > 0].  y None + beta: the mask is recomputed with bn_relu_forward's own expression -- the bits of
+    the y it wrote, without reading it."""
     lib = _lib.load()
     gy, t = _dev(gy, "gy"), _dev(t, "t")
     y = None if y is None else _dev(y, "y")
@@ -707,7 +708,8 @@ def bn_relu_backward(gy, t, y, gamma, mean, rstd, relu=True, dgamma_out=None, db
         rc = lib.lcrec_bn_relu_backward(_ptr(gy), _ptr(t), _ptr(y), n, F, _ptr(gamma), _ptr(_vec(mean, "mean", F)),
                                         _ptr(_vec(rstd, "rstd", F)), int(bool(relu)), _ptr(dt), _ptr(dgamma), _ptr(dbeta),
                                         _ptr(dbias), _ptr(None if fold is None else _vec(fold[0], "fold_scale", F)),
-                                        _ptr(None if fold is None else _vec(fold[1], "fold_shift", F)), _stream_ptr())
+                                        _ptr(_vec(fold[1], "fold_shift", F) if fold is not None else
+                                             (_vec(beta, "beta", F) if (y is None and beta is not None) else None)), _stream_ptr())
     _lib.check(rc, "lcrec_bn_relu_backward")
     return dt, dgamma, dbeta, dbias
 

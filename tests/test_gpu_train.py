@@ -53,6 +53,11 @@ def test_bn_relu_forward_backward_match_torch(hip, n, feat, relu):
     np.testing.assert_allclose(db.cpu().numpy(), bd.grad.numpy(), rtol=1e-5, atol=1e-4)
     # the Linear bias in front of a BatchNorm has gradient sum(dt) = 0 up to rounding
     assert float(dbias.abs().max()) <= 1e-5 * n * max(scale, 1.0)
+    # without y: the mask recomputed from t by the forward's own expression -- the same bits
+    if relu:
+        again = hip.ops.bn_relu_backward(d(gy), d(t), None, d(gamma), mean, rstd, relu=True, beta=d(beta))
+        for a, b in zip(again, (dt, dg, db, dbias)):
+            assert torch.equal(a, b)
     # deterministic: same bits on a second run
     y2, _, _ = hip.ops.bn_relu_forward(d(t), d(gamma), d(beta), 1e-5, 0.1, None, None, relu=relu)
     assert torch.equal(y2, y)
