@@ -168,6 +168,9 @@ int lcrec_linear_backward(const float *gy, const float *x, const float *W, int64
  * exactly what lcrec_linear_backward computes for that layer -- the same S = lcrec_linear_backward_splits runs, added in
  * order -- so the results are bit-identical to per-layer calls.  A training step's narrow layers are a handful of tiles
  * each; launched together their workgroups fill the chip (index/trainer.py:117: autograd produces these one at a time).
+ * A problem's `splits` field (> 0) sets its S itself -- the same definition of the runs and of their sum, another S.  A
+ * launch of a whole step's problems has thousands of tiles, and cutting the narrow layers' batches there only adds partial
+ * products to write, read and add (the training engine passes 1: one fma chain over the batch per element).
  * `problems` is a HOST array; all pointers inside are device pointers.  Widths must be multiples of 4. */
 typedef struct {
     const float *gy;   /* [n][out_dim] gradient w.r.t. the layer's pre-activation output */
@@ -180,6 +183,7 @@ typedef struct {
      * and (x_scale, x_shift) that BatchNorm's folded affine; u is formed on the operand's way into LDS. */
     const float *x_scale, *x_shift;
     int x_relu;
+    int splits;        /* ABI 3: 0 = S of lcrec_linear_backward_splits(n, in_dim, out_dim); > 0 = this S (at most ceil(n/32)) */
 } lcrec_dw_problem;
 size_t lcrec_linear_backward_weights_workspace(const lcrec_dw_problem *problems, int count);
 int lcrec_linear_backward_weights(const lcrec_dw_problem *problems, int count, void *workspace, size_t workspace_bytes,

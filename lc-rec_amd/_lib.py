@@ -103,7 +103,7 @@ class DwProblem(ctypes.Structure):
     """lcrec_dw_problem of include/lcrec.h"""
     _fields_ = [("gy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("gw", ctypes.c_void_p), ("n", ctypes.c_int64),
                 ("in_dim", ctypes.c_int), ("out_dim", ctypes.c_int), ("x_scale", ctypes.c_void_p), ("x_shift", ctypes.c_void_p),
-                ("x_relu", ctypes.c_int)]
+                ("x_relu", ctypes.c_int), ("splits", ctypes.c_int)]
 
 
 class TraceEntry(ctypes.Structure):

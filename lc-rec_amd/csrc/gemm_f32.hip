@@ -1904,10 +1904,25 @@ int linear_backward(const float *gy, const float *x, const float *W, int64_t n, 
 
 // ---- grouped weight gradients (lcrec_linear_backward_weights): same S and run lengths per problem as linear_backward,
 // hence the same bits; one launch for the products, one for the ordered sums of their K-runs
+// K-runs of problem q: its `splits` field when set (normalised so that no run is empty), else the per-layer rule
+static int dw_problem_splits(const lcrec_dw_problem &q)
+{
+    if (q.splits <= 0) return linear_backward_splits(q.n, q.in_dim, q.out_dim);
+    const int64_t nk = (q.n + BK - 1) / BK;
+    const int64_t s = q.splits < nk ? q.splits : (nk > 0 ? nk : 1);
+    const int64_t per = (nk + s - 1) / s;
+    return per > 0 ? (int)((nk + per - 1) / per) : 1;
+}
+static size_t dw_problem_workspace(const lcrec_dw_problem &q)
+{
+    const int s = dw_problem_splits(q);
+    return s > 1 ? (size_t)s * q.out_dim * q.in_dim * sizeof(float) : 0;
+}
+
 size_t linear_backward_weights_workspace(const lcrec_dw_problem *pr, int count)
 {
     size_t total = 0;
-    for (int i = 0; i < count; ++i) total += align_up(linear_backward_workspace(pr[i].n, pr[i].in_dim, pr[i].out_dim), 256);
+    for (int i = 0; i < count; ++i) total += align_up(dw_problem_workspace(pr[i]), 256);
     return total;
 }
 
@@ -1935,7 +1950,7 @@ int linear_backward_weights(const lcrec_dw_problem *pr, int count, void *workspa
         const int64_t widest = q.in_dim > q.out_dim ? q.in_dim : q.out_dim;
         if ((q.n + 64) * widest * 4 >= (1ll << 31) || (int64_t)q.out_dim * q.in_dim * 4 >= (1ll << 31))
             return fail(LCREC_EUNSUPPORTED, "linear_backward_weights: problem %d exceeds the 2 GiB a buffer descriptor spans", i);
-        const int splits = linear_backward_splits(q.n, q.in_dim, q.out_dim);
+        const int splits = dw_problem_splits(q);
         const int nk = (int)((q.n + BK - 1) / BK);
         const int64_t bm_blocks = (q.out_dim + 63) / 64;
         const int bn_blocks = (q.in_dim + 63) / 64;
@@ -1953,7 +1968,7 @@ int linear_backward_weights(const lcrec_dw_problem *pr, int count, void *workspa
         wg += (unsigned)(tiles * (splits > 1 ? splits : 1));
         if (splits > 1) {
             float *partial = reinterpret_cast<float *>(ws);
-            ws += align_up(linear_backward_workspace(q.n, q.in_dim, q.out_dim), 256);
+            ws += align_up(dw_problem_workspace(q), 256);
             g.C[i] = partial;
             const int j = r.count++;
             r.partial[j] = partial; r.out[j] = q.gw; r.splits[j] = splits;

@@ -37,6 +37,8 @@ reset is due run eagerly.  Data-parallel runs use the same line with the exchang
 engine does not cover falls back to the autograd path in trainer.py, unchanged: dropout > 0, activations other than ReLU,
 optimisers other than Adam/AdamW, --strict_nan_check (the reference's per-step host sync).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -44,6 +46,11 @@ from . import ops
 from .quantize import level_plan, quantize_values
 
 _ALIGN = 64     # floats: every parameter starts on a 256-byte boundary of the flat buffers
+
+
+# K-runs per weight gradient in the step's grouped launch: 1 = one chain over the batch (0 = lcrec_linear_backward_splits' per-layer
+# rule; LCREC_DW_SPLITS, tuning)
+DW_SPLITS = int(os.environ.get("LCREC_DW_SPLITS", "1"))
 
 
 class TrainEngine:
@@ -295,7 +302,7 @@ class TrainEngine:
         dw = []
         g_xq = self._mlp_backward(dec, g_out, True, dw)
         if world is not None and self._late_span is not None:
-            ops.linear_backward_weights(dw)                                  # the decoder's weight gradients, one launch ...
+            ops.linear_backward_weights(dw, splits=DW_SPLITS)                # the decoder's weight gradients, one launch ...
             dw = []
             lo, hi = self._late_span                                         # ... and its span of the flat buffer is on its way
             works.append(world.all_reduce_(self.flat_g[lo:hi], async_op=True))
@@ -306,7 +313,7 @@ class TrainEngine:
         stats = ops.code_stats_levels(q["idx"], q["resid_in"], [c.shape[0] for c in cbs], cbs,
                                       [self.grad_view[lvl.embedding.weight] for lvl in levels], scale, m.quant_loss_weight)
         self._mlp_backward(enc, gz, False, dw)
-        ops.linear_backward_weights(dw)                                      # all 14 weight gradients, one launch
+        ops.linear_backward_weights(dw, splits=DW_SPLITS)                    # all 14 weight gradients, one launch: 2 000 tiles, one chain each
         del dw
         if world is not None:
             for lo, hi in self._early_spans:

@@ -257,11 +257,12 @@ def linear_backward(gy, x, weight, need_gx=True, need_gw=True, gw_out=None):
     return gx, gw
 
 
-def linear_backward_weights(problems):
+def linear_backward_weights(problems, splits=0):
     """Weight gradients of several Linear layers in ONE launch (lcrec_linear_backward_weights): `problems` is a list of
     (gy [n, out], x [n, in], gw_out [out, in]) device tensors; every gw_out is written in place, bit-identical to what
     linear_backward(gy, x, W, need_gx=False) computes for that layer.  A fourth entry (scale, shift, relu) makes the layer
-    input max(x * scale + shift, 0 if relu) -- x being a pre-BatchNorm tensor of lcrec_linear_bn_forward -- formed on the fly."""
+    input max(x * scale + shift, 0 if relu) -- x being a pre-BatchNorm tensor of lcrec_linear_bn_forward -- formed on the fly.
+    splits > 0: that many K-runs over the batch for every problem instead of lcrec_linear_backward_splits' (1 = one chain)."""
     lib = _lib.load()
     count = len(problems)
     if count == 0:
@@ -277,11 +278,11 @@ def linear_backward_weights(problems):
         if x.shape[0] != n or tuple(gw.shape) != (out_dim, in_dim) or not gw.is_contiguous() or gw.dtype != torch.float32:
             raise _lib.LcrecError(f"linear_backward_weights: problem {i}: gy {tuple(gy.shape)}, x {tuple(x.shape)}, gw {tuple(gw.shape)}")
         if fold is None:
-            arr[i] = _lib.DwProblem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), n, in_dim, out_dim, None, None, 0)
+            arr[i] = _lib.DwProblem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), n, in_dim, out_dim, None, None, 0, int(splits))
         else:
             fs, fh = _vec(fold[0], "x_scale", in_dim), _vec(fold[1], "x_shift", in_dim)
             arr[i] = _lib.DwProblem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), n, in_dim, out_dim, fs.data_ptr(), fh.data_ptr(),
-                                    int(bool(fold[2])))
+                                    int(bool(fold[2])), int(splits))
             keep += [fs, fh]
         keep += [gy, x]
     dev = problems[0][0].device

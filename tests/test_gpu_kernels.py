@@ -138,6 +138,16 @@ def test_grouped_weight_gradients_equal_per_layer_calls(hip, oracle):
     one = torch.empty((2048, 768), device=dev)
     hip.ops.linear_backward_weights([(problems[0][0], problems[0][1], one)])
     assert torch.equal(one, problems[0][2])
+    # `splits` sets every problem's S itself: 1 = one fma chain over the batch per element (what the training engine asks for),
+    # 3 = three runs added in order -- against the oracle's sums with that S, narrow and wide layers alike
+    for S in (1, 3):
+        picked = [problems[i] for i in (2, 4, 6, 8, 14)]
+        outs = [torch.full_like(p[2], float("nan")) for p in picked]
+        hip.ops.linear_backward_weights([(p[0], p[1], o) for p, o in zip(picked, outs)], splits=S)
+        for (gy, x, _), o in zip(picked, outs):
+            _, w = oracle.linear_backward(gy.cpu().numpy(), x.cpu().numpy(), np.zeros((gy.shape[1], x.shape[1]), np.float32),
+                                          splits=S, threads=8)
+            assert torch.equal(o, torch.from_numpy(w).to(dev)), (S, tuple(o.shape))
     with pytest.raises(hip.LcrecError):
         hip.ops.linear_backward_weights([problems[0]] * 17)
 
