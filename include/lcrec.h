@@ -428,6 +428,12 @@ int lcrec_step_losses(const double *sse, int L, int64_t n, int e, float beta, fl
  * level-0 index column (element i at idx[i*idx_stride]); all [n][e]. */
 int lcrec_quantizer_input_grad(const float *z, const float *codebook0, const int64_t *idx, int64_t idx_stride, int64_t n,
                                int e, float coef, float weight, const float *g_xq, float *out, void *stream);
+/* The same, and dbias_out[e] = the column sums of `out`: the gradient of the bias of the encoder's last Linear, which has no
+ * BatchNorm and no activation behind it (index/models/layers.py:19-30 skips both on the last layer), so what reaches z reaches
+ * its pre-activation unchanged -- one launch for what lcrec_quantizer_input_grad + lcrec_relu_bias_backward(relu = 0) do in two.
+ * dbias_out NULL: lcrec_quantizer_input_grad. */
+int lcrec_quantizer_input_grad_bias(const float *z, const float *codebook0, const int64_t *idx, int64_t idx_stride, int64_t n,
+                                    int e, float coef, float weight, const float *g_xq, float *out, float *dbias_out, void *stream);
 
 /* One optimiser step on flat fp32 buffers: torch.optim.AdamW (decoupled != 0) or Adam (index/trainer.py:49-81,119),
  * preceded by the clipping of index/trainer.py:118 (grads *= clip[1], stored back; clip may be NULL) and with the

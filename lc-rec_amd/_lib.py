@@ -86,6 +86,8 @@ _SIGNATURES = {
                                          _vp, _vp, _vp, _vp]),
     "lcrec_quantizer_input_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_float, _vp, _vp, _vp]),
+    "lcrec_quantizer_input_grad_bias": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                                       ctypes.c_float, _vp, _vp, _vp, _vp]),
     "lcrec_adamw_step": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _vp]),

@@ -500,6 +500,12 @@ LCREC_API int lcrec_quantizer_input_grad(const float *z, const float *codebook0,
     return quantizer_input_grad(z, codebook0, idx, idx_stride, n, e, coef, weight, g_xq, out, (hipStream_t)stream);
 }
 
+LCREC_API int lcrec_quantizer_input_grad_bias(const float *z, const float *codebook0, const int64_t *idx, int64_t idx_stride, int64_t n,
+                                              int e, float coef, float weight, const float *g_xq, float *out, float *dbias_out, void *stream)
+{
+    return quantizer_input_grad_bias(z, codebook0, idx, idx_stride, n, e, coef, weight, g_xq, out, dbias_out, (hipStream_t)stream);
+}
+
 LCREC_API int lcrec_code_stats_levels(const int64_t *idx, const float *const *resid, int64_t n, int e, const int *K, int L,
                                       float *const *count, float *const *sum, const float *const *codebooks, float *const *grad_out,
                                       float scale, float weight, void *stream)

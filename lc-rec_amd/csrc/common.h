@@ -249,6 +249,8 @@ int step_losses(const double *sse, int L, int64_t n, int e, float beta, float ql
                 unsigned char *nan_flag, const int64_t *probe, unsigned char *probe_flag, hipStream_t stream);
 int quantizer_input_grad(const float *z, const float *cb0, const int64_t *idx, int64_t idx_stride, int64_t n, int e, float coef,
                          float weight, const float *g_xq, float *out, hipStream_t stream);
+int quantizer_input_grad_bias(const float *z, const float *cb0, const int64_t *idx, int64_t idx_stride, int64_t n, int e, float coef,
+                              float weight, const float *g_xq, float *out, float *dbias, hipStream_t stream);
 int codebook_grad(const float *count, const float *sum, const float *cb, int K, int e, float scale, float weight, float *grad,
                   hipStream_t stream);
 int adamw_step(float *p, float *g, float *m, float *v, int64_t count, const float *clip, int64_t *step, double base_lr,

@@ -958,6 +958,49 @@ __global__ __launch_bounds__(256) void quantizer_input_grad_kernel(const float *
     }
 }
 
+// The same with the column sums of `out` beside it (dbias of the encoder's last Linear, which has neither BatchNorm nor an
+// activation behind it: its bias gradient is the column sum of the gradient reaching z): ONE workgroup, thread (row group, column),
+// rows ascending per lane, row groups added in order through LDS.  For batch-sized n (n * e <= 64 K elements).
+constexpr int QGB_THREADS = 1024;
+__global__ __launch_bounds__(QGB_THREADS) void quantizer_input_grad_bias_kernel(const float *__restrict__ z, const float *__restrict__ cb0,
+                                                                                const int64_t *__restrict__ idx, int64_t idx_stride, int n,
+                                                                                int e, float coef, float weight,
+                                                                                const float *__restrict__ g_xq, float *__restrict__ out,
+                                                                                float *__restrict__ dbias)
+{
+    __shared__ float part[QGB_THREADS];
+    const int c = threadIdx.x % e, rg = threadIdx.x / e, rgs = QGB_THREADS / e;      // e divides 1024 (16, 32, 64)
+    float acc = 0.f;
+    for (int r0 = rg; r0 < n; r0 += 4 * rgs) {                // four rows' loads in flight
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * rgs;
+            const int rr = r < n ? r : rg;                    // (a valid row: rg < n whenever this loop runs)
+            const int64_t i = (int64_t)rr * e + c;
+            const float t = z[i] - cb0[idx[(int64_t)rr * idx_stride] * e + c];
+            const float uu = coef * t;
+            const float w = uu * weight;
+            v[u] = w + g_xq[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * rgs;
+            if (r < n) {
+                out[(int64_t)r * e + c] = v[u];
+                acc += v[u];
+            }
+        }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < e) {
+        float s = part[threadIdx.x];
+        for (int g = 1; g < rgs; ++g) s += part[g * e + threadIdx.x];
+        dbias[threadIdx.x] = s;
+    }
+}
+
 // dL/dC[k][:] = (scale * (count[k] * C[k][:] - sum[k][:])) * weight -- the closed form autograd derives from vq.py:90-92
 // (SURVEY.md a9), in the order quantize.py evaluates it
 __global__ __launch_bounds__(256) void codebook_grad_kernel(const float *__restrict__ count, const float *__restrict__ sum,
@@ -1227,6 +1270,24 @@ int quantizer_input_grad(const float *z, const float *cb0, const int64_t *idx, i
     hipLaunchKernelGGL(quantizer_input_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, cb0, idx, idx_stride, n, e, coef, weight,
                        g_xq, out);
     return check_launch("quantizer_input_grad_kernel");
+}
+
+int quantizer_input_grad_bias(const float *z, const float *cb0, const int64_t *idx, int64_t idx_stride, int64_t n, int e, float coef,
+                              float weight, const float *g_xq, float *out, float *dbias, hipStream_t stream)
+{
+    if (!dbias) return quantizer_input_grad(z, cb0, idx, idx_stride, n, e, coef, weight, g_xq, out, stream);
+    if (n == 0) return LCREC_OK;
+    if (!z || !cb0 || !idx || !g_xq || !out) return fail(LCREC_EINVAL, "quantizer_input_grad_bias: NULL pointer");
+    if (n < 0 || e < 1) return fail(LCREC_EINVAL, "quantizer_input_grad_bias: bad shape");
+    if ((e == 16 || e == 32 || e == 64) && n * e <= 65536) {
+        TraceScope trace(K_APPLY_LEVEL, stream);
+        hipLaunchKernelGGL(quantizer_input_grad_bias_kernel, dim3(1), dim3(QGB_THREADS), 0, stream, z, cb0, idx, idx_stride, (int)n, e, coef,
+                           weight, g_xq, out, dbias);
+        return check_launch("quantizer_input_grad_bias_kernel");
+    }
+    // other shapes: the two launches this call stands for
+    if (int rc = quantizer_input_grad(z, cb0, idx, idx_stride, n, e, coef, weight, g_xq, out, stream)) return rc;
+    return relu_bias_backward(out, nullptr, n, e, 0, nullptr, dbias, stream);
 }
 
 int codebook_grad(const float *count, const float *sum, const float *cb, int K, int e, float scale, float weight, float *grad,

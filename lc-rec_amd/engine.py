@@ -229,7 +229,7 @@ class TrainEngine:
             raise ops._lib.LcrecError("engine: the last layer of an MLP has no BatchNorm (layers.py:19-30)")
         return h, saved
 
-    def _mlp_backward(self, saved, g, need_input_grad, dw):
+    def _mlp_backward(self, saved, g, need_input_grad, dw, last_bias_done=False):
         """The dX chain of one MLP: BatchNorm/ReLU backward -> dX GEMM -> next layer.  Weight gradients are leaves of the
         dependency graph and most of them are a handful of tiles: they are queued in `dw` as (dt, layer input, gradient
         view[, input fold]) and computed by ONE grouped launch at the end of the step (lcrec_linear_backward_weights)."""
@@ -249,6 +249,8 @@ class TrainEngine:
                                                    dgamma_out=gv[bn.weight], dbeta_out=gv[bn.bias], dbias_out=gv[lin.bias],
                                                    fold=None if y is not None else out_fold[:2],
                                                    beta=bn.bias.data if recompute else None)
+            elif last_bias_done and i == len(saved) - 1 and not relu:
+                dt = g                                   # g is the pre-activation gradient already and the bias gradient is written
             else:
                 dt, _ = ops.relu_bias_backward(g, y, relu, dbias_out=gv[lin.bias], inplace=True)
             dw.append((dt, h, gv[lin.weight]) if in_fold is None else (dt, h, gv[lin.weight], in_fold))
@@ -308,11 +310,16 @@ class TrainEngine:
             works.append(world.all_reduce_(self.flat_g[lo:hi], async_op=True))
             self.collectives += 1
         scale = 2.0 / (len(levels) * n * e)                                  # quantize.py: d mean-level-loss / d (sum of squares)
-        gz = ops.quantizer_input_grad(z, cbs[0], q["idx"][:, 0], float(m.rq.beta) * scale, m.quant_loss_weight, g_xq)
+        # (the encoder's last Linear has neither BatchNorm nor activation behind it: what reaches z is the gradient of its
+        # pre-activation, and its bias gradient -- the column sums -- comes out of the same launch)
+        last = enc[-1]
+        bias_here = last[2] is None and not last[3]
+        gz = ops.quantizer_input_grad(z, cbs[0], q["idx"][:, 0], float(m.rq.beta) * scale, m.quant_loss_weight, g_xq,
+                                      dbias_out=self.grad_view[last[1].bias] if bias_here else None)
         # per-code (count, sum) of every level and the codebook gradients (scale * (cnt*C - sum)) * g_loss: one launch
         stats = ops.code_stats_levels(q["idx"], q["resid_in"], [c.shape[0] for c in cbs], cbs,
                                       [self.grad_view[lvl.embedding.weight] for lvl in levels], scale, m.quant_loss_weight)
-        self._mlp_backward(enc, gz, False, dw)
+        self._mlp_backward(enc, gz, False, dw, last_bias_done=bias_here)
         ops.linear_backward_weights(dw, splits=DW_SPLITS)                    # all 14 weight gradients, one launch: 2 000 tiles, one chain each
         del dw
         if world is not None:

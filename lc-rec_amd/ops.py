@@ -876,16 +876,21 @@ def step_losses(sse, n, e, beta, quant_loss_weight, recon, losses_out, sums=None
     return losses_out
 
 
-def quantizer_input_grad(z, codebook0, idx_col, coef, weight, g_xq):
-    """(coef * (z - C0[idx0])) * weight + g_xq (lcrec_quantizer_input_grad)."""
+def quantizer_input_grad(z, codebook0, idx_col, coef, weight, g_xq, dbias_out=None):
+    """(coef * (z - C0[idx0])) * weight + g_xq (lcrec_quantizer_input_grad); with dbias_out [e] also its column sums, the bias
+    gradient of the encoder's last Linear, in the same launch (lcrec_quantizer_input_grad_bias)."""
     lib = _lib.load()
     z, codebook0, g_xq = _dev(z, "z"), _dev(codebook0, "codebook"), _dev(g_xq, "g_xq")
     n, e = z.shape
     idx_col, stride = _idx_col(idx_col, n)
     out = torch.empty_like(z)
     with _on(z.device):
-        rc = lib.lcrec_quantizer_input_grad(_ptr(z), _ptr(codebook0), _ptr(idx_col), stride, n, e, float(coef), float(weight),
-                                            _ptr(g_xq), _ptr(out), _stream_ptr())
+        if dbias_out is None:
+            rc = lib.lcrec_quantizer_input_grad(_ptr(z), _ptr(codebook0), _ptr(idx_col), stride, n, e, float(coef), float(weight),
+                                                _ptr(g_xq), _ptr(out), _stream_ptr())
+        else:
+            rc = lib.lcrec_quantizer_input_grad_bias(_ptr(z), _ptr(codebook0), _ptr(idx_col), stride, n, e, float(coef), float(weight),
+                                                     _ptr(g_xq), _ptr(out), _ptr(_vec(dbias_out, "dbias_out", e)), _stream_ptr())
     _lib.check(rc, "lcrec_quantizer_input_grad")
     return out
 

@@ -63,6 +63,24 @@ def test_bn_relu_forward_backward_match_torch(hip, n, feat, relu):
     assert torch.equal(y2, y)
 
 
+def test_quantizer_input_grad_with_bias_gradient(hip):
+    """lcrec_quantizer_input_grad_bias: the values of lcrec_quantizer_input_grad bit for bit, and their column sums (the encoder's
+    last bias gradient) against fp64; batch sizes the one-workgroup kernel takes and one it hands to the two-launch form."""
+    dev = torch.device(DEV)
+    g = torch.Generator(device=dev).manual_seed(3)
+    for n, e in ((1024, 32), (475, 32), (2048, 16), (70000, 32), (1000, 64)):
+        z = torch.randn((n, e), generator=g, device=dev)
+        cb = torch.randn((256, e), generator=g, device=dev)
+        idx = torch.randint(0, 256, (n, 4), generator=g, device=dev)
+        gx = torch.randn((n, e), generator=g, device=dev) * 1e-3
+        plain = hip.ops.quantizer_input_grad(z, cb, idx[:, 0], 0.25 * 2e-5, 1.0, gx)
+        dbias = torch.full((e,), float("nan"), device=dev)
+        both = hip.ops.quantizer_input_grad(z, cb, idx[:, 0], 0.25 * 2e-5, 1.0, gx, dbias_out=dbias)
+        assert torch.equal(both, plain)
+        want = plain.double().sum(0)
+        np.testing.assert_allclose(dbias.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(plain.abs().sum(0).max()))
+
+
 @pytest.mark.parametrize("cuts,feat,relu", [((0, 60, 120, 175), 96, True), ((0, 1, 9, 1024), 2048, True), ((0, 500, 500, 777), 100, False)])
 def test_sharded_batchnorm_kernels_give_the_whole_batch_result(hip, cuts, feat, relu):
     """The data-parallel split of the BatchNorm step (lcrec_bn_stats -> exchange -> lcrec_bn_merge_stats -> lcrec_bn_relu_apply;
